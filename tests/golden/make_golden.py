@@ -1,0 +1,333 @@
+#!/usr/bin/env python3
+"""Regenerate the golden vectors in this directory from the *reference* package.
+
+Run only in the build container, where the reference source tree is mounted
+read-only at /root/reference (it never travels to the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Every array written here is DATA: inputs (generated below with this repo's own
+generators, or produced by the reference's own test fixture
+``rotated_classes_dataset``) and the outputs the reference computes for them.
+Both float64 ("_f64") and float32 ("_f32") reference outputs are stored, the
+float32 ones so that tests can use the reference's own f32-vs-f64 deviation as
+the yardstick.
+
+Groups:
+  G1  per-evaluation affine-invariant distances, loss, dloss/dS      (a1-a6, a9, a11)
+  G1x cross batches A != B with a weighted-sum loss                    (a1-a6)
+  G2  Calvo-Oller / Fisher-Rao lower bound from (means, covariances)   (a7, a8)
+  G3  closure: get_class_distances + loss + grad wrt the raw parameter (a12)
+  G4  fit trajectories (loss per epoch, final filters)
+  G5  quirks: pca_from_scatter, class_statistics, squeeze shapes, eigenvalue order
+"""
+import os
+import sys
+
+import numpy as np
+
+REF_SRC = "/root/reference/src"
+REF_TESTS = "/root/reference/tests"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF_SRC)
+sys.path.insert(0, REF_TESTS)
+
+import torch  # noqa: E402
+
+import sqfa  # noqa: E402  (the reference)
+from make_examples import rotated_classes_dataset  # noqa: E402  (reference test fixture -> data)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(4)
+
+
+# ---------------------------------------------------------------- input generators (ours)
+def random_spd(rng, n, m, lo=0.02, hi=3.0):
+    """n SPD matrices m x m with log-uniform spectrum in [lo, hi] and Haar eigenvectors."""
+    out = np.empty((n, m, m))
+    for k in range(n):
+        q, r = np.linalg.qr(rng.standard_normal((m, m)))
+        q = q * np.sign(np.diag(r))
+        ev = np.exp(rng.uniform(np.log(lo), np.log(hi), m))
+        out[k] = (q * ev) @ q.T
+        out[k] = 0.5 * (out[k] + out[k].T)
+    return out
+
+
+def T(x, dtype):
+    return torch.tensor(np.asarray(x), dtype=dtype)
+
+
+def tril_loss(D):
+    C = D.shape[0]
+    idx = torch.tril_indices(C, C, offset=-1)
+    return -torch.mean(D[idx[0], idx[1]])
+
+
+# ---------------------------------------------------------------- G1
+def g1():
+    rng = np.random.default_rng(20251003)
+    out = {}
+    cases = [(2, 2), (5, 2), (5, 3), (8, 4), (10, 5), (16, 8), (12, 9), (10, 16), (9, 17),
+             (6, 32), (5, 33), (3, 1), (7, 6), (20, 12), (4, 24), (3, 48), (3, 64), (37, 16)]
+    out["cases"] = np.array(cases)
+    for (C, m) in cases:
+        S = random_spd(rng, C, m)
+        key = f"C{C}_m{m}"
+        out[f"{key}_S"] = S
+        for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            St = T(S, dt).requires_grad_(True)
+            dsq = sqfa.distances.affine_invariant_sq(St, St)
+            d = sqfa.distances.affine_invariant(St, St)
+            loss = tril_loss(d)
+            (g,) = torch.autograd.grad(loss, St, retain_graph=True)
+            loss_sq = tril_loss(dsq)
+            (gsq,) = torch.autograd.grad(loss_sq, St)
+            out[f"{key}_dsq_{tag}"] = dsq.detach().numpy()
+            out[f"{key}_d_{tag}"] = d.detach().numpy()
+            out[f"{key}_loss_{tag}"] = loss.detach().numpy()
+            out[f"{key}_grad_{tag}"] = g.numpy()
+            out[f"{key}_loss_sq_{tag}"] = loss_sq.detach().numpy()
+            out[f"{key}_grad_sq_{tag}"] = gsq.numpy()
+    np.savez_compressed(os.path.join(HERE, "g1_airm_self.npz"), **out)
+
+
+def g1x():
+    rng = np.random.default_rng(77)
+    out = {}
+    cases = [(1, 1, 3), (1, 4, 4), (4, 1, 2), (4, 8, 6), (8, 4, 4), (5, 7, 16), (19, 3, 9), (6, 6, 17)]
+    out["cases"] = np.array(cases)
+    for (nA, nB, m) in cases:
+        A = random_spd(rng, nA, m)
+        B = random_spd(rng, nB, m)
+        W = rng.standard_normal((nA, nB))
+        key = f"A{nA}_B{nB}_m{m}"
+        out[f"{key}_A"], out[f"{key}_B"], out[f"{key}_W"] = A, B, W
+        for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            At = T(A, dt).requires_grad_(True)
+            Bt = T(B, dt).requires_grad_(True)
+            Wt = T(W, dt)
+            lam = sqfa.linalg.generalized_eigenvalues(At, Bt)
+            dsq = sqfa.distances.affine_invariant_sq(At, Bt)
+            d = sqfa.distances.affine_invariant(At, Bt)
+            out[f"{key}_lam_{tag}"] = lam.detach().numpy()
+            out[f"{key}_dsq_{tag}"] = dsq.detach().numpy()
+            out[f"{key}_d_{tag}"] = d.detach().numpy()
+            for name, mat in (("d", d), ("dsq", dsq)):
+                loss = torch.sum(Wt.reshape(mat.shape) * mat)
+                gA, gB = torch.autograd.grad(loss, (At, Bt), retain_graph=True)
+                out[f"{key}_gA_{name}_{tag}"] = gA.numpy()
+                out[f"{key}_gB_{name}_{tag}"] = gB.numpy()
+    np.savez_compressed(os.path.join(HERE, "g1x_airm_cross.npz"), **out)
+
+
+# ---------------------------------------------------------------- G2
+def g2():
+    rng = np.random.default_rng(4242)
+    out = {}
+    cases = [(2, 1), (5, 2), (8, 4), (16, 8), (9, 16), (5, 32), (11, 7)]
+    out["cases"] = np.array(cases)
+    for (C, K) in cases:
+        cov = random_spd(rng, C, K)
+        mu = 0.7 * rng.standard_normal((C, K))
+        key = f"C{C}_K{K}"
+        out[f"{key}_cov"], out[f"{key}_mu"] = cov, mu
+        for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            covt = T(cov, dt).requires_grad_(True)
+            mut = T(mu, dt).requires_grad_(True)
+            st = {"means": mut, "covariances": covt}
+            emb = sqfa.distances._embed_gaussian(st)
+            frsq = sqfa.distances.fisher_rao_lower_bound_sq(st, st)
+            fr = sqfa.distances.fisher_rao_lower_bound(st, st)
+            loss = tril_loss(fr)
+            gmu, gcov = torch.autograd.grad(loss, (mut, covt), retain_graph=True)
+            loss_sq = tril_loss(frsq)
+            gmu_sq, gcov_sq = torch.autograd.grad(loss_sq, (mut, covt))
+            out[f"{key}_emb_{tag}"] = emb.detach().numpy()
+            out[f"{key}_frsq_{tag}"] = frsq.detach().numpy()
+            out[f"{key}_fr_{tag}"] = fr.detach().numpy()
+            out[f"{key}_loss_{tag}"] = loss.detach().numpy()
+            out[f"{key}_gmu_{tag}"] = gmu.numpy()
+            out[f"{key}_gcov_{tag}"] = gcov.numpy()
+            out[f"{key}_loss_sq_{tag}"] = loss_sq.detach().numpy()
+            out[f"{key}_gmu_sq_{tag}"] = gmu_sq.numpy()
+            out[f"{key}_gcov_sq_{tag}"] = gcov_sq.numpy()
+    np.savez_compressed(os.path.join(HERE, "g2_fisher_rao.npz"), **out)
+
+
+# ---------------------------------------------------------------- G3
+def synthetic_stats(rng, C, D, rank):
+    cov = np.empty((C, D, D))
+    for c in range(C):
+        A = rng.standard_normal((D, rank)) / np.sqrt(rank)
+        cov[c] = A @ A.T + 0.05 * np.eye(D)
+    mu = 0.3 * rng.standard_normal((C, D))
+    return mu, cov
+
+
+def g3():
+    rng = np.random.default_rng(303)
+    out = {}
+    rot = rotated_classes_dataset().double().numpy()
+    out["rotated_cov"] = rot
+    mu_rot = 0.2 * rng.standard_normal((rot.shape[0], rot.shape[1]))
+    out["rotated_mu"] = mu_rot
+    raw = {K: rng.standard_normal((K, 8)) for K in (1, 2, 3, 4)}
+    for K, v in raw.items():
+        out[f"raw_filters_K{K}"] = v
+    for model_name in ("smsqfa", "sqfa"):
+        for constraint in ("sphere", "none", "orthogonal"):
+            for noise in (0.0, 1e-3, 1e-2):
+                for K in (1, 2, 3, 4):
+                    for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+                        torch.set_default_dtype(dt)
+                        cls = sqfa.model.SQFA if model_name == "sqfa" else sqfa.model.SecondMomentsSQFA
+                        model = cls(n_dim=8, n_filters=K, feature_noise=noise, constraint=constraint)
+                        if dt == torch.float64:
+                            model = model.double()
+                        # assign the raw parameter directly (bypassing right_inverse) so that the
+                        # builder can do the same
+                        with torch.no_grad():
+                            prm = model.parametrizations.filters.original
+                            prm.copy_(T(raw[K], dt))
+                        stats = {"means": T(mu_rot, dt), "covariances": T(rot, dt)}
+                        inp = stats if model_name == "sqfa" else T(rot, dt)
+                        key = f"{model_name}_{constraint}_n{noise:g}_K{K}"
+                        try:
+                            D_ = model.get_class_distances(inp, regularized=True)
+                        except Exception as err:  # the reference itself fails on this combo
+                            print("  skipped", key, tag, type(err).__name__)
+                            continue
+                        loss = tril_loss(D_)
+                        model.zero_grad()
+                        loss.backward()
+                        out[f"{key}_filters_{tag}"] = model.filters.detach().numpy()
+                        out[f"{key}_D_{tag}"] = D_.detach().numpy()
+                        out[f"{key}_loss_{tag}"] = loss.detach().numpy()
+                        out[f"{key}_grad_{tag}"] = prm.grad.detach().numpy()
+    torch.set_default_dtype(torch.float32)
+    np.savez_compressed(os.path.join(HERE, "g3_closure.npz"), **out)
+
+
+# ---------------------------------------------------------------- G4
+def g4():
+    out = {}
+    rot = rotated_classes_dataset().double()
+    rng = np.random.default_rng(404)
+    mu20, cov20 = synthetic_stats(rng, 20, 50, 10)
+    out["syn_mu"], out["syn_cov"] = mu20, cov20
+    out["rotated_cov"] = rot.numpy()
+    torch.set_default_dtype(torch.float64)
+    datasets = {
+        "rot": {"means": torch.zeros(5, 8), "covariances": rot},
+        "syn": {"means": T(mu20, torch.float64), "covariances": T(cov20, torch.float64)},
+    }
+    for dname, stats in datasets.items():
+        n_dim = stats["covariances"].shape[-1]
+        for model_name in ("smsqfa", "sqfa"):
+            for (K, noise) in ((2, 1e-3), (4, 1e-2)):
+                for epochs in (1, 3, 300):
+                    cls = sqfa.model.SQFA if model_name == "sqfa" else sqfa.model.SecondMomentsSQFA
+                    model = cls(n_dim=n_dim, n_filters=K, feature_noise=noise).double()
+                    model.fit_pca(data_statistics=stats)
+                    init = model.filters.detach().clone().numpy()
+                    loss, _t = model.fit(data_statistics=stats, max_epochs=epochs,
+                                         show_progress=False, return_loss=True)
+                    key = f"{dname}_{model_name}_K{K}_e{epochs}"
+                    out[f"{key}_init"] = init
+                    out[f"{key}_loss"] = loss.numpy()
+                    out[f"{key}_filters"] = model.filters.detach().numpy()
+        # pairwise run
+        for model_name in ("smsqfa", "sqfa"):
+            cls = sqfa.model.SQFA if model_name == "sqfa" else sqfa.model.SecondMomentsSQFA
+            model = cls(n_dim=n_dim, n_filters=4, feature_noise=1e-2).double()
+            model.fit_pca(data_statistics=stats)
+            loss, _t = model.fit(data_statistics=stats, max_epochs=300, pairwise=True,
+                                 show_progress=False, return_loss=True)
+            key = f"{dname}_{model_name}_pairwise_K4"
+            out[f"{key}_loss"] = loss.numpy()
+            out[f"{key}_filters"] = model.filters.detach().numpy()
+    # float32 short trajectories (first 3 epochs) for the f32 criterion of SURVEY 8c
+    torch.set_default_dtype(torch.float32)
+    for dname, stats in datasets.items():
+        st32 = {k: v.float() for k, v in stats.items()}
+        n_dim = st32["covariances"].shape[-1]
+        for model_name in ("smsqfa", "sqfa"):
+            cls = sqfa.model.SQFA if model_name == "sqfa" else sqfa.model.SecondMomentsSQFA
+            model = cls(n_dim=n_dim, n_filters=4, feature_noise=1e-2)
+            model.fit_pca(data_statistics=st32)
+            key = f"{dname}_{model_name}_K4_e3_f32"
+            try:
+                loss, _t = model.fit(data_statistics=st32, max_epochs=3, show_progress=False, return_loss=True)
+            except Exception as err:  # the reference's own float32 run diverges on this dataset
+                print("  skipped", key, type(err).__name__)
+                continue
+            out[f"{key}_loss"] = loss.numpy()
+            out[f"{key}_filters"] = model.filters.detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "g4_fit.npz"), **out)
+
+
+# ---------------------------------------------------------------- G5
+def g5():
+    out = {}
+    torch.set_default_dtype(torch.float64)
+    rot = rotated_classes_dataset().double()
+    out["rotated_cov"] = rot.numpy()
+    for K in (1, 2, 4, 8):
+        out[f"pca_from_scatter_K{K}"] = sqfa.statistics.pca_from_scatter(rot, K).numpy()
+    rng = np.random.default_rng(55)
+    X = rng.standard_normal((120, 6)) @ rng.standard_normal((6, 6))
+    y = np.repeat(np.arange(4), 30)
+    perm = rng.permutation(120)
+    X, y = X[perm], y[perm]
+    out["pts_X"], out["pts_y"] = X, y
+    for est in ("empirical", "oas"):
+        st = sqfa.statistics.class_statistics(T(X, torch.float64), torch.tensor(y), estimator=est)
+        for k, v in st.items():
+            out[f"class_stats_{est}_{k}"] = v.numpy()
+    out["pca_X_K3"] = sqfa.statistics.pca(T(X, torch.float64), 3).numpy()
+    out["oas_cov"] = sqfa.statistics.oas_covariance(T(X, torch.float64)).numpy()
+    out["sample_cov"] = sqfa.statistics.sample_covariance(T(X, torch.float64)).numpy()
+    # squeeze shapes
+    spd = random_spd(rng, 4, 3)
+    shapes = []
+    for nA in (1, 4):
+        for nB in (1, 4):
+            A = T(spd[:nA], torch.float64)
+            B = T(spd[:nB], torch.float64)
+            shapes.append([nA, nB,
+                           len(sqfa.distances.affine_invariant_sq(A, B).shape),
+                           len(sqfa.linalg.generalized_eigenvalues(A, B).shape)])
+    out["squeeze_shapes"] = np.array(shapes)
+    out["squeeze_2d_A"] = np.array(sqfa.distances.affine_invariant_sq(T(spd[0], torch.float64),
+                                                                     T(spd[:4], torch.float64)).shape)
+    # other linalg helpers
+    out["spd"] = spd
+    out["spd_sqrt"] = sqfa.linalg.spd_sqrt(T(spd, torch.float64)).numpy()
+    out["spd_log"] = sqfa.linalg.spd_log(T(spd, torch.float64)).numpy()
+    W = sqfa.linalg.spd_inv_sqrt(T(spd, torch.float64))
+    out["spd_inv_sqrt_whitened"] = torch.einsum("nij,njk,nlk->nil", W, T(spd, torch.float64), W).numpy()
+    gv, ge = sqfa.linalg.generalized_eigenvectors(T(spd[:3], torch.float64), T(spd[1:4], torch.float64))
+    out["gen_eigvec_abs"] = gv.abs().numpy()
+    out["gen_eigval"] = ge.numpy()
+    # remaining distance_fun operators: values only
+    cov = random_spd(rng, 5, 4)
+    mu = rng.standard_normal((5, 4))
+    out["dist_cov"], out["dist_mu"] = cov, mu
+    st = {"means": T(mu, torch.float64), "covariances": T(cov, torch.float64)}
+    out["log_euclidean_sq"] = sqfa.distances.log_euclidean_sq(st["covariances"], st["covariances"]).numpy()
+    out["log_euclidean"] = sqfa.distances.log_euclidean(st["covariances"], st["covariances"]).numpy()
+    for name in ("bhattacharyya", "mahalanobis_sq", "mahalanobis", "hellinger", "fisher_rao_same_cov"):
+        out[name] = getattr(sqfa.distances, name)(st, st).numpy()
+    torch.set_default_dtype(torch.float32)
+    np.savez_compressed(os.path.join(HERE, "g5_quirks.npz"), **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g1x", "g2", "g3", "g4", "g5"]
+    for name in which:
+        print("generating", name, flush=True)
+        globals()[name]()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
