@@ -1,0 +1,113 @@
+/*
+ * sqfa_hip.h -- C ABI of libsqfa_hip.so, the MI355X (gfx950) implementation of the
+ * SQFA pairwise SPD-distance hot path.
+ *
+ * Plain C, plain pointers and sizes; no torch / C++ types cross this boundary.
+ * All data pointers are DEVICE pointers (HBM) unless stated otherwise; all work is
+ * enqueued on `stream` (a hipStream_t passed as void*), nothing synchronises.
+ *
+ * What each entry point replaces in the reference (paths relative to the
+ * reference repository root):
+ *
+ *   sqfa_airm_pairwise   the whole chain executed per closure evaluation
+ *       spd_inv_sqrt               src/sqfa/linalg.py:144-162   (per-class whitening)
+ *       conjugate_matrix           src/sqfa/linalg.py:19-45     (all-pairs W_j A_i W_j^T)
+ *       generalized_eigenvalues    src/sqfa/linalg.py:48-70     (batched eigvalsh + flip)
+ *       affine_invariant_sq        src/sqfa/distances.py:46-67  (sum log^2)
+ *       affine_invariant           src/sqfa/distances.py:70-89  (sqrt(. + 1e-6))
+ *       fisher_rao_lower_bound[_sq] src/sqfa/distances.py:177-237 (scale = 1/2 on embeddings)
+ *       closure loss               src/sqfa/_optim.py:88-96     (-mean over i>j) via uniform_weight
+ *       check_distances_valid      src/sqfa/_optim.py:16-30     via nonfinite_out
+ *       autograd backward of all of the above (torch LinalgEighBackward0 x2, BmmBackward)
+ *                                  via gradA_out / gradB_out (closed form)
+ *
+ * The reference-side binding a maintainer would add is shown in INTEGRATION.md.
+ */
+#ifndef SQFA_HIP_H
+#define SQFA_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* element types */
+#define SQFA_F32 0
+#define SQFA_F64 1
+
+/* status codes (return values) */
+#define SQFA_OK                 0
+#define SQFA_ERR_BAD_ARGUMENT  -1   /* null pointer, negative size, bad dtype, bad shard ... */
+#define SQFA_ERR_UNSUPPORTED_M -2   /* m outside [1, sqfa_hip_max_dim()] */
+#define SQFA_ERR_WORKSPACE     -3   /* workspace_bytes smaller than sqfa_airm_workspace_bytes() */
+#define SQFA_ERR_LAUNCH        -4   /* a HIP launch failed; see sqfa_hip_last_error() */
+
+/* Library / build identification. */
+int sqfa_hip_version(void);            /* 1000*major + minor */
+const char *sqfa_hip_arch(void);       /* "gfx950" */
+int sqfa_hip_max_dim(void);            /* largest matrix size m handled natively */
+const char *sqfa_hip_last_error(void); /* text of the last HIP error seen by this library (host thread local) */
+
+/*
+ * Tile geometry used for a given problem, so that callers can shard work
+ * (multi-GPU) and size buffers:  tiles form an n_tiles_i x n_tiles_j grid over
+ * (A classes) x (B classes); tile (bi,bj) is processed by the call iff
+ * (bi + bj) % shard_count == shard_index (and, in self mode, it contains a pair i>j).
+ * Returns SQFA_OK or an error code.
+ */
+int sqfa_airm_tiling(int nA, int nB, int m, int dtype,
+                     int *tile_i, int *tile_j, int *n_tiles_i, int *n_tiles_j, int *padded_m);
+
+/* Bytes of device workspace sqfa_airm_pairwise needs for this problem (0 on error). */
+size_t sqfa_airm_workspace_bytes(int nA, int nB, int m, int dtype);
+
+/*
+ * Pairwise affine-invariant distances between two batches of SPD matrices, the
+ * weighted sum of those distances, and the gradient of that sum.
+ *
+ *   A        (nA, m, m) row-major contiguous SPD matrices (dtype)
+ *   B        (nB, m, m) or NULL.  NULL (with nB == 0) selects SELF mode: B is A and
+ *            only the unordered pairs i > j are evaluated (the reference evaluates
+ *            all ordered pairs and then keeps i > j, src/sqfa/_optim.py:94).
+ *   scale    d2 = scale * sum_k log(lambda_k)^2      (1 for AIRM, 0.5 for Calvo-Oller)
+ *   eps      D = sqrt(d2 + eps) when sqrt_mode != 0, else D = d2
+ *   pair_weights  NULL, or (nA, nB) row-major (dtype): w_ij.  In SELF mode the weight
+ *            of the unordered pair {i,j} is w_ij + w_ji.
+ *   uniform_weight  used when pair_weights == NULL: every evaluated pair has this
+ *            weight (e.g. -1/P for the closure loss, P the GLOBAL pair count).
+ *   shard_index, shard_count   tile shard processed by this call (0,1 = everything).
+ *   loss_out      (1) dtype: sum over evaluated pairs of w * D          (may be NULL)
+ *   gradA_out     (nA, m, m) dtype: d loss / d A (SELF mode: full gradient wrt the
+ *                 shared batch).  NULL = forward only (no eigenvectors kept).
+ *   gradB_out     (nB, m, m) dtype, cross mode only (ignored / may be NULL in SELF mode)
+ *   dist_out      (nA, nB) dtype: D_ij for evaluated pairs; SELF mode also writes D_ji
+ *                 and the diagonal (sqrt(eps) or 0).  Entries of tiles outside the shard
+ *                 are left untouched.                                       (may be NULL)
+ *   eig_out       (nA, nB, m) dtype: generalized eigenvalues of (A_i, B_j), UNSORTED;
+ *                 SELF mode mirrors 1/lambda into (j,i) and writes ones on the diagonal.
+ *                                                                           (may be NULL)
+ *   nonfinite_out (2) int32: {#pairs with D = NaN, #pairs with D = +-inf} among the
+ *                 evaluated pairs                                           (may be NULL)
+ *   workspace     device scratch of at least sqfa_airm_workspace_bytes() bytes
+ *   stream        hipStream_t
+ *
+ * Outputs of this shard only; a multi-GPU caller sums loss/grad/nonfinite over shards.
+ * Results are bitwise reproducible run to run for fixed inputs and sharding.
+ */
+int sqfa_airm_pairwise(const void *A, int nA, const void *B, int nB, int m, int dtype,
+                       double scale, double eps, int sqrt_mode,
+                       const void *pair_weights, double uniform_weight,
+                       int shard_index, int shard_count,
+                       void *loss_out, void *gradA_out, void *gradB_out,
+                       void *dist_out, void *eig_out, int *nonfinite_out,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* Debug/introspection: average Jacobi sweeps per wave-round of the last call is
+ * written to sweeps_out[0] (float, device) if a buffer was registered; pass NULL to disable. */
+int sqfa_airm_set_sweep_counter(unsigned long long *device_counter2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SQFA_HIP_H */

@@ -1,0 +1,163 @@
+"""torch <-> C-ABI glue for the pairwise SPD-distance kernels.
+
+torch is used for device memory, streams and autograd bookkeeping only; all arithmetic of
+the hot path happens inside libsqfa_hip.so.  Tests may install a different *pair backend*
+(``set_pair_backend``) to exercise the host logic without a GPU; the default backend is
+the HIP library and it refuses CPU tensors.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+EPSILON = 1e-6  # value added inside square roots (reference: src/sqfa/distances.py:29)
+
+
+def _dtype_code(t):
+    if t.dtype == torch.float32:
+        return _lib.SQFA_F32
+    if t.dtype == torch.float64:
+        return _lib.SQFA_F64
+    raise TypeError(f"sqfa_amd kernels support float32 and float64, got {t.dtype}")
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def max_dim():
+    return _lib.load().sqfa_hip_max_dim()
+
+
+def hip_pair_backend(A, B, *, scale, eps, sqrt_mode, weights, uniform_weight, shard,
+                     want_loss, want_grad, want_dist, want_eig):
+    """Run sqfa_airm_pairwise on the current stream.  A (nA,m,m); B (nB,m,m) or None (self).
+    Returns dict(loss, gradA, gradB, dist, eig, nonfinite) of freshly allocated tensors
+    (None where not requested)."""
+    lib = _lib.load()
+    if not A.is_cuda:
+        raise RuntimeError(
+            "sqfa_amd computes pairwise SPD distances on the GPU only (no CPU fallback): "
+            "move the statistics/model to a HIP device, or pass your own distance_fun."
+        )
+    if B is not None and (B.device != A.device or B.dtype != A.dtype):
+        raise ValueError("A and B must share device and dtype")
+    A = A.detach().contiguous()
+    nA, m = A.shape[0], A.shape[-1]
+    if B is not None:
+        B = B.detach().contiguous()
+        nB = B.shape[0]
+    else:
+        nB = 0
+    code = _dtype_code(A)
+    if m > lib.sqfa_hip_max_dim():
+        raise NotImplementedError(
+            f"matrix size {m} exceeds the largest size the native kernels handle ({lib.sqfa_hip_max_dim()})"
+        )
+    nbytes = lib.sqfa_airm_workspace_bytes(nA, nB, m, code)
+    if nbytes == 0:
+        raise _lib.NativeLibraryError("sqfa_airm_workspace_bytes rejected the problem shape")
+    dev = A.device
+    nBe = nA if B is None else nB
+    with torch.cuda.device(dev):
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        loss = torch.zeros((), dtype=A.dtype, device=dev) if want_loss else None
+        nonfinite = torch.zeros(2, dtype=torch.int32, device=dev)
+        gradA = torch.empty_like(A) if want_grad else None
+        gradB = torch.empty_like(B) if (want_grad and B is not None) else None
+        if want_dist:
+            dist = (torch.zeros if shard[1] > 1 else torch.empty)((nA, nBe), dtype=A.dtype, device=dev)
+        else:
+            dist = None
+        eig = torch.empty((nA, nBe, m), dtype=A.dtype, device=dev) if want_eig else None
+        if weights is not None:
+            weights = weights.detach().to(dtype=A.dtype, device=dev).contiguous()
+            if tuple(weights.shape) != (nA, nBe):
+                raise ValueError("pair weights must have shape (nA, nB)")
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        status = lib.sqfa_airm_pairwise(
+            _ptr(A), nA, _ptr(B), nB, m, code,
+            float(scale), float(eps), int(bool(sqrt_mode)),
+            _ptr(weights), float(uniform_weight),
+            int(shard[0]), int(shard[1]),
+            _ptr(loss), _ptr(gradA), _ptr(gradB), _ptr(dist), _ptr(eig), _ptr(nonfinite),
+            _ptr(ws), nbytes, ctypes.c_void_p(stream),
+        )
+    _lib.check(status, "sqfa_airm_pairwise")
+    return {"loss": loss, "gradA": gradA, "gradB": gradB, "dist": dist, "eig": eig, "nonfinite": nonfinite}
+
+
+_pair_backend = hip_pair_backend
+
+
+def set_pair_backend(fn):
+    """Install a different pair backend (tests only).  Pass None to restore the HIP one."""
+    global _pair_backend
+    _pair_backend = hip_pair_backend if fn is None else fn
+
+
+def pair_backend():
+    return _pair_backend
+
+
+# ------------------------------------------------------------------------------------------
+# autograd wrappers
+
+
+class PairDistanceMatrix(torch.autograd.Function):
+    """D[i,j] = dist(A_i, B_j) as a differentiable (nA,nB) matrix.  The backward pass
+    re-evaluates the pairs with the incoming gradient as per-pair weights (nothing of
+    size nA*nB*m*m is ever stored)."""
+
+    @staticmethod
+    def forward(ctx, A, B, scale, eps, sqrt_mode):
+        out = _pair_backend(A, B, scale=scale, eps=eps, sqrt_mode=sqrt_mode, weights=None,
+                            uniform_weight=0.0, shard=(0, 1), want_loss=False, want_grad=False,
+                            want_dist=True, want_eig=False)
+        ctx.save_for_backward(A, B if B is not None else A.new_empty(0))
+        ctx.self_mode = B is None
+        ctx.cfg = (scale, eps, sqrt_mode)
+        ctx.mark_non_differentiable(out["nonfinite"])
+        return out["dist"], out["nonfinite"]
+
+    @staticmethod
+    def backward(ctx, gD, _gflag):
+        A, B = ctx.saved_tensors
+        B = None if ctx.self_mode else B
+        scale, eps, sqrt_mode = ctx.cfg
+        out = _pair_backend(A, B, scale=scale, eps=eps, sqrt_mode=sqrt_mode, weights=gD,
+                            uniform_weight=0.0, shard=(0, 1), want_loss=False, want_grad=True,
+                            want_dist=False, want_eig=False)
+        return out["gradA"], out["gradB"], None, None, None
+
+
+class PairwiseLoss(torch.autograd.Function):
+    """Fused closure loss: sum over the unordered pairs i>j of  weight * dist(S_i, S_j)
+    (weight = -1/P gives the reference's -mean, src/sqfa/_optim.py:94) together with its
+    gradient, in one pass.  `reducer(loss, nonfinite, grad)` combines shards (all-reduce)."""
+
+    @staticmethod
+    def forward(ctx, S, scale, eps, sqrt_mode, weight, shard, reducer):
+        out = _pair_backend(S, None, scale=scale, eps=eps, sqrt_mode=sqrt_mode, weights=None,
+                            uniform_weight=weight, shard=shard, want_loss=True, want_grad=True,
+                            want_dist=False, want_eig=False)
+        loss, nonfinite, grad = out["loss"], out["nonfinite"], out["gradA"]
+        if reducer is not None:
+            loss, nonfinite, grad = reducer(loss, nonfinite, grad)
+        ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(nonfinite)
+        return loss, nonfinite
+
+    @staticmethod
+    def backward(ctx, gloss, _gflag):
+        (grad,) = ctx.saved_tensors
+        return grad * gloss, None, None, None, None, None, None
+
+
+def generalized_eigenvalues_raw(A, B):
+    """(nA,nB,m) generalized eigenvalues of (A_i, B_j), descending.  Not differentiable."""
+    out = _pair_backend(A, B, scale=1.0, eps=EPSILON, sqrt_mode=False, weights=None,
+                        uniform_weight=0.0, shard=(0, 1), want_loss=False, want_grad=False,
+                        want_dist=False, want_eig=True)
+    return torch.sort(out["eig"], dim=-1, descending=True).values

@@ -1,0 +1,12 @@
+// pair_inst.hip -- one explicit instantiation of the pair tile kernel per translation unit.
+// Compiled once per configuration with -DSQFA_T=.. -DSQFA_TAG=.. -DSQFA_MR=.. -DSQFA_G=.. -DSQFA_CPL=.. -DSQFA_TJ=.. -DSQFA_WAVES=..
+#include "pair_kernel.hpp"
+
+#define SQFA_CAT_(a, b, c) a##b##_##c
+#define SQFA_CAT(a, b, c) SQFA_CAT_(a, b, c)
+
+namespace sqfa {
+hipError_t SQFA_CAT(launch_pair_, SQFA_TAG, SQFA_MR)(const PairParams& p, hipStream_t stream) {
+  return launch_pair_tiles<PairCfg<SQFA_T, SQFA_MR, SQFA_G, SQFA_CPL, SQFA_TJ, SQFA_WAVES>>(p, stream);
+}
+}  // namespace sqfa

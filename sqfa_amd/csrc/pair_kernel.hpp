@@ -1,0 +1,504 @@
+// pair_kernel.hpp -- the pairwise affine-invariant distance tile kernel for gfx950.
+//
+// One workgroup (4 wave64) owns a TI x TJ tile of (A class, B class) pairs.  Inside a
+// wave, G adjacent lanes co-operate on one pair ("lane group"); a wave therefore works
+// on 64/G pairs at once, all sharing the same B class j (so L_j^-1 is wave-uniform and
+// is fetched through the scalar cache), with TI = 64/G different A classes i.
+//
+// Per pair (A = S_i, B = S_j = L_j L_j^T):
+//   1. X = L_j^-1 L_i                  (lower triangular; M = X X^T = L_j^-1 A L_j^-T)
+//   2. one-sided (Hestenes) Jacobi on the COLUMNS of X, held in registers: each lane owns
+//      CPL column slots of all MR rows; rotations between columns of one lane are local,
+//      rotations between lanes use an XOR tournament (lane^s, slot^t) through DPP.
+//      On exit X J = Y with orthogonal columns y_k = sigma_k v_k: lambda_k = |y_k|^2 are
+//      the generalized eigenvalues of (A,B), v_k the eigenvectors of M.
+//   3. d2 = scale * sum log(lambda)^2, D = sqrt(d2+eps) | d2
+//   4. backward (closed form, SURVEY.md 3.4 / oracle/closed_form.py): with
+//      u~_k = L_j^-T y_k:  dL/dA += sum_k (g_k/lambda_k) u~ u~^T,  dL/dB -= sum_k g_k u~ u~^T,
+//      g_k = w * dD/dd2 * scale * 2 log(lambda_k)/lambda_k.
+//      A-side sums are kept per wave in LDS (private, deterministic), B-side sums are
+//      reduced over the whole wave (all its pairs share j).  Tiles flush lower triangles
+//      to a slab in HBM; a second kernel reduces slabs per class in a fixed order.
+//
+// Replaces: src/sqfa/linalg.py:19-70,144-162, src/sqfa/distances.py:46-89,177-237,
+// src/sqfa/_optim.py:16-30,88-96 of the reference and the autograd backward of that chain.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sqfa {
+
+struct PairParams {
+  const void* LT;     // [nA][MR*MR]  LT[c][k] = L_A[k][c]  (columns of L contiguous), identity padded
+  const void* Linv;   // [nB][MR*MR]  row-major inverse Cholesky factor of B, identity padded
+  const void* W;      // optional (nA,nB) pair weights, or nullptr
+  void* slab_grad;    // [nbi*nbj][TI+TJ][TRI]
+  void* slab_loss;    // [nbi*nbj]
+  int* slab_flag;     // [nbi*nbj][2]  {NaN count, inf count}
+  void* dist_out;     // (nA,nB) or nullptr
+  void* eig_out;      // (nA,nB,m) or nullptr
+  unsigned long long* sweep_counter;  // optional debug counter {sum of sweeps, wave rounds}
+  int nA, nB, m;
+  int self_mode, sqrt_mode, want_grad;
+  int shard_index, shard_count;
+  int nbi, nbj;
+  double scale, eps, uniform_weight;
+};
+
+__host__ __device__ constexpr int pow2ceil(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+__host__ __device__ constexpr int tri_index(int r, int c) { return r * (r + 1) / 2 + c; }  // r >= c
+
+// ---------------------------------------------------------------------------------------
+// scalar helpers
+template <typename T> struct Real;
+template <> struct Real<float> {
+  static constexpr float kEps = 1.1920929e-07f;
+  static constexpr float kEarly2 = 1.0e-7f;  // (3.2e-4)^2: sweep in which every |cos| stays below -> last sweep
+  static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+  static __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+  static __device__ __forceinline__ float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
+  static __device__ __forceinline__ float abs_(float x) { return __builtin_fabsf(x); }
+  static __device__ __forceinline__ float copysign_(float a, float b) { return __builtin_copysignf(a, b); }
+  static __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+  static __device__ __forceinline__ float log_(float x) { return logf(x); }
+  static __device__ __forceinline__ bool finite(float x) { return __builtin_isfinite(x); }
+};
+template <> struct Real<double> {
+  static constexpr double kEps = 2.220446049250313e-16;
+  static constexpr double kEarly2 = 1.0e-15;
+  static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+  static __device__ __forceinline__ double rsq(double x) { return 1.0 / sqrt(x); }
+  static __device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
+  static __device__ __forceinline__ double abs_(double x) { return __builtin_fabs(x); }
+  static __device__ __forceinline__ double copysign_(double a, double b) { return __builtin_copysign(a, b); }
+  static __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+  static __device__ __forceinline__ double log_(double x) { return log(x); }
+  static __device__ __forceinline__ bool finite(double x) { return __builtin_isfinite(x); }
+};
+
+// ---------------------------------------------------------------------------------------
+// cross-lane movement.  DPP controls: quad_perm [1,0,3,2]=0xB1 (xor 1), [2,3,0,1]=0x4E (xor 2),
+// [3,2,1,0]=0x1B (xor 3), row_half_mirror=0x141, row_mirror=0x140.
+template <int CTRL> __device__ __forceinline__ int dpp_mov_i(int v) {
+  return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, dpp_mov_i<CTRL>(__builtin_bit_cast(int, v)));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  return __hiloint2double(dpp_mov_i<CTRL>(hi), dpp_mov_i<CTRL>(lo));
+}
+
+// value held by lane (lane ^ S).  S > 0: compile-time partner (DPP when S <= 3);
+// S == 0: runtime partner `s` (LDS crossbar).
+template <int S, typename T> __device__ __forceinline__ T lane_xor(T v, int s) {
+  if constexpr (S == 1) return dpp_mov<0xB1>(v);
+  else if constexpr (S == 2) return dpp_mov<0x4E>(v);
+  else if constexpr (S == 3) return dpp_mov<0x1B>(v);
+  else if constexpr (S == 0) return __shfl_xor(v, s, 64);
+  else return __shfl_xor(v, S, 64);
+}
+
+// sum over the G lanes of a lane group (every lane gets the total)
+template <int G, typename T> __device__ __forceinline__ T group_sum(T v) {
+  if constexpr (G >= 2) v += dpp_mov<0xB1>(v);
+  if constexpr (G >= 4) v += dpp_mov<0x4E>(v);
+  if constexpr (G >= 8) v += dpp_mov<0x141>(v);   // quads are uniform now: half mirror == xor 4
+  if constexpr (G >= 16) v += dpp_mov<0x140>(v);  // row mirror == xor 8
+  if constexpr (G >= 32) v += __shfl_xor(v, 16, 64);
+  if constexpr (G >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+// sum over all 64 lanes, fixed association order (deterministic)
+template <typename T> __device__ __forceinline__ T wave_sum(T v) { return group_sum<64>(v); }
+
+// ---------------------------------------------------------------------------------------
+// Jacobi rotation parameters for "my" column (squared norm no) against a partner column
+// (squared norm nr) with inner product gam.  Symmetric formulation: both owners evaluate
+// this with their own (no, nr) and apply  x' = cs*x - sn*x_partner,  no' = no - tl*gam.
+template <typename T>
+__device__ __forceinline__ void rot_params(T no, T nr, T gam, T tol2, T& cs, T& sn, T& tl, bool& big) {
+  using R = Real<T>;
+  const T ab = no * nr;
+  const T g2 = gam * gam;
+  const bool rot = g2 > tol2 * ab;
+  big = big || (g2 > R::kEarly2 * ab);
+  const T zeta = (nr - no) * (T(0.5) * R::rcp(gam));
+  const T w = R::sqrt_(R::fma_(zeta, zeta, T(1)));
+  T t = R::copysign_(R::rcp(R::abs_(zeta) + w), zeta);
+  const T c = R::rsq(R::fma_(t, t, T(1)));
+  tl = rot ? t : T(0);
+  cs = rot ? c : T(1);
+  sn = tl * cs;
+}
+
+// one tournament round against the lane group member (lane ^ s): every column slot c of
+// mine meets slot (c ^ t) of the partner, t = 0..pow2ceil(CPL)-1.
+//
+// For t != 0 slots c and cp = c^t are handled together: pair a = (my c, partner's cp) and
+// pair b = (my cp, partner's c).  The partner evaluates the same code, so its <x_c, my x_cp>
+// is my pair-b inner product: it is fetched with one cross-lane move instead of MR FMAs.
+// Slot c is rotated first (standard form, old partner values); slot cp is rotated afterwards
+// against the partner's ALREADY ROTATED slot c with the algebraically equivalent form
+//   x' = x/cs - tl * x_partner_new        (from x' = cs x - sn q, q = (q' - sn... ) / cs)
+// so only one MR-long temporary is live at a time.
+template <typename T, int MR, int CPL, int S>
+__device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], int s, T tol2, bool& big) {
+  using R = Real<T>;
+  constexpr int TP2 = pow2ceil(CPL);
+#pragma unroll
+  for (int t = 0; t < TP2; ++t) {
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const int cp = c ^ t;
+      if (cp < c || cp >= CPL) continue;  // resolved at compile time after unrolling
+      T rv[MR];
+#pragma unroll
+      for (int r = 0; r < MR; ++r) rv[r] = lane_xor<S>(x[cp][r], s);  // partner's slot cp
+      T gam1 = T(0);
+#pragma unroll
+      for (int r = 0; r < MR; ++r) gam1 = R::fma_(x[c][r], rv[r], gam1);
+      const T nr1 = lane_xor<S>(nrm[cp], s);
+      T cs1, sn1, tl1;
+      if (cp == c) {
+        rot_params(nrm[c], nr1, gam1, tol2, cs1, sn1, tl1, big);
+#pragma unroll
+        for (int r = 0; r < MR; ++r) x[c][r] = cs1 * x[c][r] - sn1 * rv[r];
+        nrm[c] -= tl1 * gam1;
+      } else {
+        const T gam2 = lane_xor<S>(gam1, s);
+        const T nr2 = lane_xor<S>(nrm[c], s);
+        T cs2, sn2, tl2;
+        rot_params(nrm[c], nr1, gam1, tol2, cs1, sn1, tl1, big);
+        rot_params(nrm[cp], nr2, gam2, tol2, cs2, sn2, tl2, big);
+#pragma unroll
+        for (int r = 0; r < MR; ++r) x[c][r] = cs1 * x[c][r] - sn1 * rv[r];
+        const T ics2 = R::fma_(tl2, tl2, T(1)) * cs2;  // 1/cs2 (cs2 = rsq(1+tl2^2); both 1 when not rotating)
+#pragma unroll
+        for (int r = 0; r < MR; ++r) rv[r] = lane_xor<S>(x[c][r], s);  // partner's slot c, rotated
+#pragma unroll
+        for (int r = 0; r < MR; ++r) x[cp][r] = ics2 * x[cp][r] - tl2 * rv[r];
+        nrm[c] -= tl1 * gam1;
+        nrm[cp] -= tl2 * gam2;
+      }
+    }
+  }
+}
+
+template <typename T, int MR, int G, int CPL, int S>
+__device__ __forceinline__ void cross_rounds_static(T (&x)[CPL][MR], T (&nrm)[CPL], T tol2, bool& big) {
+  if constexpr (S < G) {
+    cross_round<T, MR, CPL, S>(x, nrm, S, tol2, big);
+    cross_rounds_static<T, MR, G, CPL, S + 1>(x, nrm, tol2, big);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+template <typename T, int MR_, int G_, int CPL_, int TJ_, int WAVES_>
+struct PairCfg {
+  using type = T;
+  static constexpr int MR = MR_;     // padded matrix size (rows, and real columns)
+  static constexpr int G = G_;       // lanes per pair
+  static constexpr int CPL = CPL_;   // column slots per lane (G*CPL >= MR)
+  static constexpr int TJ = TJ_;     // B classes per tile
+  static constexpr int WAVES = WAVES_;  // waves per workgroup
+  static constexpr int THREADS = 64 * WAVES_;
+  static constexpr int PPW = 64 / G; // pairs per wave
+  static constexpr int TI = PPW;     // A classes per tile
+  static constexpr int TRI = MR * (MR + 1) / 2;
+  static constexpr int TRIP = TRI | 1;  // odd LDS stride between matrices
+  static constexpr int MAX_SWEEPS = 30;
+  // register budget: waves per SIMD the kernel is compiled for (256-thread blocks)
+  static constexpr int XREGS = CPL * MR * (int)(sizeof(T) / 4);
+  static constexpr int MIN_WAVES = XREGS <= 72 ? 3 : (XREGS <= 170 ? 2 : 1);
+  static_assert(G * CPL >= MR, "not enough column slots");
+  static_assert(TJ % WAVES == 0, "TJ must be a multiple of the wave count");
+};
+
+template <typename Cfg>
+__global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel(
+    const PairParams p, const typename Cfg::type* __restrict__ LT,
+    const typename Cfg::type* __restrict__ LinvAll, const typename Cfg::type* __restrict__ Wt) {
+  using T = typename Cfg::type;
+  using R = Real<T>;
+  constexpr int MR = Cfg::MR, G = Cfg::G, CPL = Cfg::CPL, TJ = Cfg::TJ, TI = Cfg::TI;
+  constexpr int WAVES = Cfg::WAVES, TRI = Cfg::TRI, TRIP = Cfg::TRIP, NT = Cfg::THREADS;
+
+  __shared__ T s_ga[WAVES * TI * TRIP];  // per-wave private A-side accumulators (lower triangles)
+  __shared__ T s_gb[TJ * TRIP];          // B-side sums, one owner wave per j
+  __shared__ T s_li[WAVES * MR * MR];    // L_j^-1 of the B class each wave is working on
+  __shared__ T s_red[WAVES];
+  __shared__ int s_redi[2 * WAVES];
+
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  const int i0 = bi * TI, j0 = bj * TJ;
+  if ((bi + bj) % p.shard_count != p.shard_index) return;
+  if (p.self_mode && (i0 + TI - 1 <= j0)) return;  // no pair with i > j in this tile
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int prob = lane / G, g = lane % G;
+  const int i = i0 + prob;
+  const int tile = bi * p.nbj + bj;
+
+  if (p.want_grad) {
+    for (int k = tid; k < WAVES * TI * TRIP; k += NT) s_ga[k] = T(0);
+    for (int k = tid; k < TJ * TRIP; k += NT) s_gb[k] = T(0);
+  }
+  __syncthreads();
+
+  const T tol2 = R::kEps * R::kEps * T(MR);
+  const T scale = T(p.scale), eps = T(p.eps);
+
+  T loss_acc = T(0);
+  int n_nan = 0, n_inf = 0;
+
+  const int ic = i < p.nA ? i : p.nA - 1;
+  const T* lt = LT + (size_t)ic * (MR * MR);
+
+  for (int jj = wave; jj < TJ; jj += WAVES) {
+    const int j = j0 + jj;  // wave-uniform
+    const bool valid = (i < p.nA) && (j < p.nB) && (!p.self_mode || i > j);
+    if (!__any(valid)) continue;
+    const int jc = __builtin_amdgcn_readfirstlane(j < p.nB ? j : p.nB - 1);
+    T* li = s_li + wave * (MR * MR);
+    {
+      const T* __restrict__ src = LinvAll + (size_t)jc * (MR * MR);
+      for (int k = lane; k < MR * MR; k += 64) li[k] = src[k];
+    }
+
+    // ---- 1. X = L_j^-1 L_i, my CPL columns ------------------------------------------
+    // columns of L_i are loaded straight into x, then multiplied in place by the lower
+    // triangular L_j^-1 (rows in descending order never read an overwritten entry)
+    T x[CPL][MR];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const int col = g * CPL + c;
+      const T* src = lt + (size_t)(col < MR ? col : 0) * MR;
+      const bool real_col = col < MR;
+#pragma unroll
+      for (int k = 0; k < MR; ++k) x[c][k] = real_col ? src[k] : T(0);
+    }
+#pragma unroll
+    for (int r = MR - 1; r >= 0; --r) {
+      T acc[CPL];
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) acc[c] = T(0);
+#pragma unroll
+      for (int k = 0; k <= r; ++k) {
+        const T l = li[r * MR + k];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc[c] = R::fma_(l, x[c][k], acc[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) x[c][r] = acc[c];
+    }
+
+    // ---- 2. one-sided Jacobi ---------------------------------------------------------
+    T nrm[CPL];
+    int sweeps = 0;
+    bool more = true;
+    while (more && sweeps < Cfg::MAX_SWEEPS) {
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        T a = T(0);
+#pragma unroll
+        for (int r = 0; r < MR; ++r) a = R::fma_(x[c][r], x[c][r], a);
+        nrm[c] = a;
+      }
+      bool big = false;
+      // pairs inside my own lane
+#pragma unroll
+      for (int c1 = 0; c1 < CPL; ++c1) {
+#pragma unroll
+        for (int c2 = c1 + 1; c2 < CPL; ++c2) {
+          T gam = T(0);
+#pragma unroll
+          for (int r = 0; r < MR; ++r) gam = R::fma_(x[c1][r], x[c2][r], gam);
+          T cs, sn, tl;
+          rot_params(nrm[c1], nrm[c2], gam, tol2, cs, sn, tl, big);
+#pragma unroll
+          for (int r = 0; r < MR; ++r) {
+            const T xp = x[c1][r], xq = x[c2][r];
+            x[c1][r] = cs * xp - sn * xq;
+            x[c2][r] = sn * xp + cs * xq;
+          }
+          nrm[c1] -= tl * gam;
+          nrm[c2] += tl * gam;
+        }
+      }
+      // pairs across the lanes of my group
+      if constexpr (G > 1 && G <= 4) {
+        cross_rounds_static<T, MR, G, CPL, 1>(x, nrm, tol2, big);
+      } else if constexpr (G > 4) {
+#pragma unroll 1
+        for (int s = 1; s < G; ++s) cross_round<T, MR, CPL, 0>(x, nrm, s, tol2, big);
+      }
+      more = __any(big);
+      ++sweeps;
+    }
+    if (p.sweep_counter != nullptr && lane == 0) {
+      atomicAdd(&p.sweep_counter[0], (unsigned long long)sweeps);
+      atomicAdd(&p.sweep_counter[1], 1ULL);
+    }
+
+    // ---- 3. eigenvalues, distance ----------------------------------------------------
+    T lam[CPL], loglam[CPL];
+    T part = T(0);
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const int col = g * CPL + c;
+      T a = T(0);
+#pragma unroll
+      for (int r = 0; r < MR; ++r) a = R::fma_(x[c][r], x[c][r], a);
+      const bool real_col = col < p.m;  // identity-padded and empty slots carry no signal
+      lam[c] = real_col ? a : T(1);
+      loglam[c] = real_col ? R::log_(a) : T(0);
+      part = R::fma_(loglam[c], loglam[c], part);
+    }
+    const T d2 = scale * group_sum<G>(part);
+    const T dist = p.sqrt_mode ? R::sqrt_(d2 + eps) : d2;
+    T w = T(0);
+    if (valid) {
+      if (Wt != nullptr) {
+        w = Wt[(size_t)i * p.nB + j];
+        if (p.self_mode) w += Wt[(size_t)j * p.nB + i];
+      } else {
+        w = T(p.uniform_weight);
+      }
+    }
+    if (valid && g == 0) {
+      loss_acc = R::fma_(w, dist, loss_acc);
+      n_nan += (dist != dist) ? 1 : 0;
+      n_inf += (dist == dist && !R::finite(dist)) ? 1 : 0;
+      if (p.dist_out != nullptr) {
+        T* D = static_cast<T*>(p.dist_out);
+        D[(size_t)i * p.nB + j] = dist;
+        if (p.self_mode) D[(size_t)j * p.nB + i] = dist;
+      }
+    }
+    if (valid && p.eig_out != nullptr) {
+      T* E = static_cast<T*>(p.eig_out);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int col = g * CPL + c;
+        if (col < p.m) {
+          E[((size_t)i * p.nB + j) * p.m + col] = lam[c];
+          if (p.self_mode) E[((size_t)j * p.nB + i) * p.m + col] = T(1) / lam[c];
+        }
+      }
+    }
+
+    // ---- 4. backward -----------------------------------------------------------------
+    if (p.want_grad) {
+      const T dd = p.sqrt_mode ? T(0.5) / dist : T(1);
+      const T coef = valid ? w * dd * scale * T(2) : T(0);
+      T coefA[CPL], coefB[CPL];
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const T q = coef * loglam[c] / lam[c];
+        coefB[c] = -q;
+        coefA[c] = q / lam[c];
+      }
+      // u~ = L_j^-T y in place: u~[r] = sum_{q>=r} Linv[q][r] y[q], rows in ascending order
+#pragma unroll
+      for (int r = 0; r < MR; ++r) {
+        T acc[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc[c] = T(0);
+#pragma unroll
+        for (int q = r; q < MR; ++q) {
+          const T l = li[q * MR + r];
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) acc[c] = R::fma_(l, x[c][q], acc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) x[c][r] = acc[c];
+      }
+      // rank-one sums, lower triangle, row by row.  After the reductions every lane of a
+      // group (A side) / of the wave (B side) holds the same value and performs the same
+      // LDS update on the same address, so no lane predicate is needed.
+      T* ga = s_ga + (size_t)(wave * TI + prob) * TRIP;
+      T* gb = s_gb + (size_t)jj * TRIP;
+#pragma unroll
+      for (int r = 0; r < MR; ++r) {
+        T sa[CPL], sb[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          sa[c] = coefA[c] * x[c][r];
+          sb[c] = coefB[c] * x[c][r];
+        }
+#pragma unroll
+        for (int cc = 0; cc <= r; ++cc) {
+          T pa = T(0), pb = T(0);
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            pa = R::fma_(sa[c], x[c][cc], pa);
+            pb = R::fma_(sb[c], x[c][cc], pb);
+          }
+          pa = group_sum<G>(pa);
+          pb = wave_sum(pb);
+          ga[tri_index(r, cc)] += pa;
+          gb[tri_index(r, cc)] = pb;
+        }
+      }
+    }
+  }
+
+  // ---- tile epilogue: flush to the slab ------------------------------------------------
+  loss_acc = wave_sum(loss_acc);
+#pragma unroll
+  for (int sh = 1; sh < 64; sh <<= 1) {
+    n_nan += __shfl_xor(n_nan, sh, 64);
+    n_inf += __shfl_xor(n_inf, sh, 64);
+  }
+  if (lane == 0) {
+    s_red[wave] = loss_acc;
+    s_redi[2 * wave] = n_nan;
+    s_redi[2 * wave + 1] = n_inf;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    T l = T(0);
+    int nn = 0, ni = 0;
+    for (int wv = 0; wv < WAVES; ++wv) {
+      l += s_red[wv];
+      nn += s_redi[2 * wv];
+      ni += s_redi[2 * wv + 1];
+    }
+    static_cast<T*>(p.slab_loss)[tile] = l;
+    p.slab_flag[2 * tile] = nn;
+    p.slab_flag[2 * tile + 1] = ni;
+  }
+  if (p.want_grad) {
+    T* slab = static_cast<T*>(p.slab_grad) + (size_t)tile * (TI + TJ) * TRI;
+    for (int k = tid; k < TI * TRI; k += NT) {
+      const int pi = k / TRI, idx = k % TRI;
+      T acc = T(0);
+#pragma unroll
+      for (int wv = 0; wv < WAVES; ++wv) acc += s_ga[(size_t)(wv * TI + pi) * TRIP + idx];
+      slab[k] = acc;
+    }
+    for (int k = tid; k < TJ * TRI; k += NT) {
+      const int pj = k / TRI, idx = k % TRI;
+      slab[TI * TRI + k] = s_gb[(size_t)pj * TRIP + idx];
+    }
+  }
+}
+
+// host-side launcher, instantiated once per configuration in its own translation unit
+template <typename Cfg>
+hipError_t launch_pair_tiles(const PairParams& p, hipStream_t stream) {
+  dim3 grid(p.nbj, p.nbi, 1);
+  using T = typename Cfg::type;
+  hipLaunchKernelGGL((pair_tile_kernel<Cfg>), grid, dim3(Cfg::THREADS), 0, stream, p, static_cast<const T*>(p.LT),
+                     static_cast<const T*>(p.Linv), static_cast<const T*>(p.W));
+  return hipGetLastError();
+}
+
+}  // namespace sqfa

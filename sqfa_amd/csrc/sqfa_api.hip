@@ -1,0 +1,340 @@
+// sqfa_api.hip -- C ABI (include/sqfa_hip.h), per-class Cholesky prologue and slab reduction.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/sqfa_hip.h"
+#include "configs.hpp"
+#include "pair_kernel.hpp"
+
+namespace sqfa {
+
+// ---- per-configuration launchers (defined in pair_inst.hip translation units) -----------
+#define SQFA_DECL_F32(T, MR, G, CPL, TJ, WV) hipError_t launch_pair_f32_##MR(const PairParams&, hipStream_t);
+#define SQFA_DECL_F64(T, MR, G, CPL, TJ, WV) hipError_t launch_pair_f64_##MR(const PairParams&, hipStream_t);
+SQFA_CONFIGS_F32(SQFA_DECL_F32)
+SQFA_CONFIGS_F64(SQFA_DECL_F64)
+
+struct Geometry {
+  int MR, G, CPL, TJ, TI;
+  hipError_t (*launch)(const PairParams&, hipStream_t);
+};
+
+static bool find_geometry(int m, int dtype, Geometry* out) {
+#define SQFA_ROW_F32(T, MR_, G_, CPL_, TJ_, WV_) \
+  if (dtype == SQFA_F32 && m <= MR_) { *out = Geometry{MR_, G_, CPL_, TJ_, 64 / G_, launch_pair_f32_##MR_}; return true; }
+#define SQFA_ROW_F64(T, MR_, G_, CPL_, TJ_, WV_) \
+  if (dtype == SQFA_F64 && m <= MR_) { *out = Geometry{MR_, G_, CPL_, TJ_, 64 / G_, launch_pair_f64_##MR_}; return true; }
+  SQFA_CONFIGS_F32(SQFA_ROW_F32)
+  SQFA_CONFIGS_F64(SQFA_ROW_F64)
+  return false;
+}
+
+static int max_dim() {
+  int mx = 0;
+#define SQFA_MAX(T, MR_, G_, CPL_, TJ_, WV_) if (MR_ > mx) mx = MR_;
+  SQFA_CONFIGS_F32(SQFA_MAX)
+  return mx;
+}
+
+static thread_local char g_last_error[256] = "";
+static unsigned long long* g_sweep_counter = nullptr;
+
+static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct WorkspaceLayout {
+  size_t off_lt, off_linv, off_slab, off_loss, off_flag, total;
+};
+
+static WorkspaceLayout layout(int nA, int nBeff, const Geometry& g, size_t esz, int nbi, int nbj) {
+  WorkspaceLayout w;
+  const size_t mat = (size_t)g.MR * g.MR * esz;
+  const size_t tri = (size_t)g.MR * (g.MR + 1) / 2;
+  size_t o = 0;
+  w.off_lt = o;   o = align_up(o + (size_t)nA * mat);
+  w.off_linv = o; o = align_up(o + (size_t)nBeff * mat);
+  w.off_slab = o; o = align_up(o + (size_t)nbi * nbj * (g.TI + g.TJ) * tri * esz);
+  w.off_loss = o; o = align_up(o + (size_t)nbi * nbj * esz);
+  w.off_flag = o; o = align_up(o + (size_t)nbi * nbj * 2 * sizeof(int));
+  w.total = o;
+  return w;
+}
+
+// ---- K0: per-class Cholesky factor and its inverse (always evaluated in double) ----------
+// One wave per class.  LT[c][col*MR + k] = L[k][col];  Linv[c][r*MR + k] = (L^-1)[r][k].
+// Both are padded to MR x MR with an identity block.  A non-SPD input produces NaNs,
+// which surface as non-finite distances (nonfinite_out), never as a fault.
+template <typename T>
+__global__ __launch_bounds__(64) void cholesky_kernel(const T* __restrict__ S, int m, int MR,
+                                                      T* __restrict__ LT, T* __restrict__ Linv) {
+  __shared__ double a[64][65];
+  __shared__ double b[64][65];
+  const int c = blockIdx.x, t = threadIdx.x;
+  const T* s = S + (size_t)c * m * m;
+  for (int idx = t; idx < m * m; idx += 64) a[idx / m][idx % m] = (double)s[idx];
+  __syncthreads();
+  for (int k = 0; k < m; ++k) {
+    const double sd = sqrt(a[k][k]);
+    __syncthreads();
+    if (t == k) a[k][k] = sd;
+    if (t > k && t < m) a[t][k] /= sd;
+    __syncthreads();
+    if (t > k && t < m) {
+      const double ltk = a[t][k];
+      for (int c2 = k + 1; c2 <= t; ++c2) a[t][c2] -= ltk * a[c2][k];
+    }
+    __syncthreads();
+  }
+  if (t < m) {  // column t of L^-1 by forward substitution
+    b[t][t] = 1.0 / a[t][t];
+    for (int r = t + 1; r < m; ++r) {
+      double acc = 0.0;
+      for (int k = t; k < r; ++k) acc += a[r][k] * b[k][t];
+      b[r][t] = -acc / a[r][r];
+    }
+  }
+  __syncthreads();
+  const size_t base = (size_t)c * MR * MR;
+  for (int idx = t; idx < MR * MR; idx += 64) {
+    const int r = idx / MR, k = idx % MR;
+    if (LT != nullptr) {  // here r = column of L, k = row of L
+      double v = (r < m && k < m) ? (k >= r ? a[k][r] : 0.0) : (r == k ? 1.0 : 0.0);
+      LT[base + idx] = (T)v;
+    }
+    if (Linv != nullptr) {
+      double v = (r < m && k < m) ? (k <= r ? b[r][k] : 0.0) : (r == k ? 1.0 : 0.0);
+      Linv[base + idx] = (T)v;
+    }
+  }
+}
+
+// ---- K2: fixed-order reduction of the tile slabs ------------------------------------------
+__device__ inline bool tile_processed(const PairParams& p, int bi, int bj, int TI, int TJ) {
+  if ((bi + bj) % p.shard_count != p.shard_index) return false;
+  if (p.self_mode && (bi * TI + TI - 1 <= bj * TJ)) return false;
+  return true;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void finalize_kernel(const PairParams p, int TI, int TJ, int MR,
+                                                       T* __restrict__ gradA, T* __restrict__ gradB,
+                                                       T* __restrict__ loss_out, int* __restrict__ nonfinite_out) {
+  const int tid = threadIdx.x;
+  const int TRI = MR * (MR + 1) / 2;
+  const int n_cls = p.nA + (p.self_mode ? 0 : p.nB);
+  const int b = blockIdx.x;
+  if (b < n_cls) {
+    if (!p.want_grad) return;
+    const bool a_side = b < p.nA;
+    const int c = a_side ? b : b - p.nA;
+    T* out = a_side ? gradA : gradB;
+    if (out == nullptr) return;
+    const T* slab = static_cast<const T*>(p.slab_grad);
+    const size_t tile_stride = (size_t)(TI + TJ) * TRI;
+    for (int idx = tid; idx < TRI; idx += 256) {
+      int r = 0;
+      while ((r + 1) * (r + 2) / 2 <= idx) ++r;
+      const int cc = idx - r * (r + 1) / 2;
+      T acc = T(0);
+      if (a_side) {
+        const int bi = c / TI, pi = c % TI;
+        for (int bj = 0; bj < p.nbj; ++bj)
+          if (tile_processed(p, bi, bj, TI, TJ)) acc += slab[(size_t)(bi * p.nbj + bj) * tile_stride + (size_t)pi * TRI + idx];
+      }
+      if (!a_side || p.self_mode) {
+        const int bj = c / TJ, pj = c % TJ;
+        for (int bi = 0; bi < p.nbi; ++bi)
+          if (tile_processed(p, bi, bj, TI, TJ)) acc += slab[(size_t)(bi * p.nbj + bj) * tile_stride + (size_t)(TI + pj) * TRI + idx];
+      }
+      if (r < p.m && cc < p.m) {
+        out[(size_t)c * p.m * p.m + (size_t)r * p.m + cc] = acc;
+        out[(size_t)c * p.m * p.m + (size_t)cc * p.m + r] = acc;
+      }
+    }
+    return;
+  }
+  // last block: loss, flag, diagonals
+  __shared__ double s_l[256];
+  __shared__ int s_f[256];
+  __shared__ int s_f2[256];
+  double l = 0.0;
+  int f = 0, f2 = 0;
+  const int ntiles = p.nbi * p.nbj;
+  for (int tix = tid; tix < ntiles; tix += 256) {
+    const int bi = tix / p.nbj, bj = tix % p.nbj;
+    if (tile_processed(p, bi, bj, TI, TJ)) {
+      l += (double)static_cast<const T*>(p.slab_loss)[tix];
+      f += p.slab_flag[2 * tix];
+      f2 += p.slab_flag[2 * tix + 1];
+    }
+  }
+  s_l[tid] = l;
+  s_f[tid] = f;
+  s_f2[tid] = f2;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) {
+      s_l[tid] += s_l[tid + st];
+      s_f[tid] += s_f[tid + st];
+      s_f2[tid] += s_f2[tid + st];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (loss_out != nullptr) loss_out[0] = (T)s_l[0];
+    if (nonfinite_out != nullptr) {
+      nonfinite_out[0] = s_f[0];
+      nonfinite_out[1] = s_f2[0];
+    }
+  }
+  if (p.self_mode) {
+    if (p.dist_out != nullptr) {
+      T* D = static_cast<T*>(p.dist_out);
+      const T dv = p.sqrt_mode ? (T)sqrt(p.eps) : T(0);
+      for (int c = tid; c < p.nA; c += 256) D[(size_t)c * p.nB + c] = dv;
+    }
+    if (p.eig_out != nullptr) {
+      T* E = static_cast<T*>(p.eig_out);
+      for (int k = tid; k < p.nA * p.m; k += 256) {
+        const int c = k / p.m, q = k % p.m;
+        E[((size_t)c * p.nB + c) * p.m + q] = T(1);
+      }
+    }
+  }
+}
+
+static int fail(int code, const char* what, hipError_t e) {
+  snprintf(g_last_error, sizeof(g_last_error), "%s: %s", what, e == hipSuccess ? "" : hipGetErrorString(e));
+  return code;
+}
+
+}  // namespace sqfa
+
+using namespace sqfa;
+
+extern "C" {
+
+int sqfa_hip_version(void) { return 1000; }
+const char* sqfa_hip_arch(void) { return "gfx950"; }
+int sqfa_hip_max_dim(void) { return max_dim(); }
+const char* sqfa_hip_last_error(void) { return g_last_error; }
+
+int sqfa_airm_set_sweep_counter(unsigned long long* device_counter2) {
+  g_sweep_counter = device_counter2;
+  return SQFA_OK;
+}
+
+int sqfa_airm_tiling(int nA, int nB, int m, int dtype, int* tile_i, int* tile_j, int* n_tiles_i,
+                     int* n_tiles_j, int* padded_m) {
+  if (nA < 1 || nB < 0 || m < 1 || (dtype != SQFA_F32 && dtype != SQFA_F64)) return SQFA_ERR_BAD_ARGUMENT;
+  Geometry g;
+  if (!find_geometry(m, dtype, &g)) return SQFA_ERR_UNSUPPORTED_M;
+  const int nBeff = nB == 0 ? nA : nB;
+  if (tile_i) *tile_i = g.TI;
+  if (tile_j) *tile_j = g.TJ;
+  if (n_tiles_i) *n_tiles_i = (nA + g.TI - 1) / g.TI;
+  if (n_tiles_j) *n_tiles_j = (nBeff + g.TJ - 1) / g.TJ;
+  if (padded_m) *padded_m = g.MR;
+  return SQFA_OK;
+}
+
+size_t sqfa_airm_workspace_bytes(int nA, int nB, int m, int dtype) {
+  int ti, tj, nbi, nbj, mr;
+  if (sqfa_airm_tiling(nA, nB, m, dtype, &ti, &tj, &nbi, &nbj, &mr) != SQFA_OK) return 0;
+  Geometry g;
+  find_geometry(m, dtype, &g);
+  const int nBeff = nB == 0 ? nA : nB;
+  return layout(nA, nBeff, g, dtype == SQFA_F32 ? 4 : 8, nbi, nbj).total;
+}
+
+int sqfa_airm_pairwise(const void* A, int nA, const void* B, int nB, int m, int dtype, double scale,
+                       double eps, int sqrt_mode, const void* pair_weights, double uniform_weight,
+                       int shard_index, int shard_count, void* loss_out, void* gradA_out,
+                       void* gradB_out, void* dist_out, void* eig_out, int* nonfinite_out,
+                       void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  g_last_error[0] = 0;
+  if (A == nullptr || nA < 1 || m < 1 || nB < 0 || workspace == nullptr) return fail(SQFA_ERR_BAD_ARGUMENT, "null/size argument", hipSuccess);
+  if (dtype != SQFA_F32 && dtype != SQFA_F64) return fail(SQFA_ERR_BAD_ARGUMENT, "dtype", hipSuccess);
+  if ((B == nullptr) != (nB == 0)) return fail(SQFA_ERR_BAD_ARGUMENT, "B and nB disagree", hipSuccess);
+  if (shard_count < 1 || shard_index < 0 || shard_index >= shard_count) return fail(SQFA_ERR_BAD_ARGUMENT, "shard", hipSuccess);
+  const bool self_mode = (B == nullptr);
+  if (self_mode && nA < 2) return fail(SQFA_ERR_BAD_ARGUMENT, "self mode needs at least two classes", hipSuccess);
+  Geometry g;
+  if (!find_geometry(m, dtype, &g)) return fail(SQFA_ERR_UNSUPPORTED_M, "matrix size not supported", hipSuccess);
+  const size_t esz = dtype == SQFA_F32 ? 4 : 8;
+  const int nBeff = self_mode ? nA : nB;
+  const int nbi = (nA + g.TI - 1) / g.TI, nbj = (nBeff + g.TJ - 1) / g.TJ;
+  const WorkspaceLayout w = layout(nA, nBeff, g, esz, nbi, nbj);
+  if (workspace_bytes < w.total) return fail(SQFA_ERR_WORKSPACE, "workspace too small", hipSuccess);
+  char* ws = static_cast<char*>(workspace);
+
+  PairParams p;
+  memset(&p, 0, sizeof(p));
+  p.LT = ws + w.off_lt;
+  p.Linv = ws + w.off_linv;
+  p.W = pair_weights;
+  p.slab_grad = ws + w.off_slab;
+  p.slab_loss = ws + w.off_loss;
+  p.slab_flag = reinterpret_cast<int*>(ws + w.off_flag);
+  p.dist_out = dist_out;
+  p.eig_out = eig_out;
+  p.sweep_counter = g_sweep_counter;
+  p.nA = nA;
+  p.nB = nBeff;
+  p.m = m;
+  p.self_mode = self_mode ? 1 : 0;
+  p.sqrt_mode = sqrt_mode ? 1 : 0;
+  p.want_grad = gradA_out != nullptr ? 1 : 0;
+  p.shard_index = shard_index;
+  p.shard_count = shard_count;
+  p.nbi = nbi;
+  p.nbj = nbj;
+  p.scale = scale;
+  p.eps = eps;
+  p.uniform_weight = uniform_weight;
+
+  // K0: factors
+  if (dtype == SQFA_F32) {
+    float* LT = reinterpret_cast<float*>(ws + w.off_lt);
+    float* LI = reinterpret_cast<float*>(ws + w.off_linv);
+    if (self_mode) {
+      hipLaunchKernelGGL(cholesky_kernel<float>, dim3(nA), dim3(64), 0, stream, static_cast<const float*>(A), m, g.MR, LT, LI);
+    } else {
+      hipLaunchKernelGGL(cholesky_kernel<float>, dim3(nA), dim3(64), 0, stream, static_cast<const float*>(A), m, g.MR, LT, (float*)nullptr);
+      hipLaunchKernelGGL(cholesky_kernel<float>, dim3(nB), dim3(64), 0, stream, static_cast<const float*>(B), m, g.MR, (float*)nullptr, LI);
+    }
+  } else {
+    double* LT = reinterpret_cast<double*>(ws + w.off_lt);
+    double* LI = reinterpret_cast<double*>(ws + w.off_linv);
+    if (self_mode) {
+      hipLaunchKernelGGL(cholesky_kernel<double>, dim3(nA), dim3(64), 0, stream, static_cast<const double*>(A), m, g.MR, LT, LI);
+    } else {
+      hipLaunchKernelGGL(cholesky_kernel<double>, dim3(nA), dim3(64), 0, stream, static_cast<const double*>(A), m, g.MR, LT, (double*)nullptr);
+      hipLaunchKernelGGL(cholesky_kernel<double>, dim3(nB), dim3(64), 0, stream, static_cast<const double*>(B), m, g.MR, (double*)nullptr, LI);
+    }
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(SQFA_ERR_LAUNCH, "cholesky_kernel", e);
+
+  // K1: pair tiles
+  e = g.launch(p, stream);
+  if (e != hipSuccess) return fail(SQFA_ERR_LAUNCH, "pair_tile_kernel", e);
+
+  // K2: slab reduction
+  const int n_cls = nA + (self_mode ? 0 : nB);
+  if (dtype == SQFA_F32) {
+    hipLaunchKernelGGL(finalize_kernel<float>, dim3(n_cls + 1), dim3(256), 0, stream, p, g.TI, g.TJ, g.MR,
+                       static_cast<float*>(gradA_out), static_cast<float*>(gradB_out),
+                       static_cast<float*>(loss_out), nonfinite_out);
+  } else {
+    hipLaunchKernelGGL(finalize_kernel<double>, dim3(n_cls + 1), dim3(256), 0, stream, p, g.TI, g.TJ, g.MR,
+                       static_cast<double*>(gradA_out), static_cast<double*>(gradB_out),
+                       static_cast<double*>(loss_out), nonfinite_out);
+  }
+  e = hipGetLastError();
+  if (e != hipSuccess) return fail(SQFA_ERR_LAUNCH, "finalize_kernel", e);
+  return SQFA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,206 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden vectors captured
+from the reference and against the CPU oracles.  Run with ``-m gpu`` on an MI355X.
+
+Tolerances (relative Frobenius unless noted):
+  float64: loss 1e-11, distances 1e-10, gradients 1e-8  (one-sided Jacobi vs LAPACK)
+  float32: loss 1e-5 (BASELINE.json north_star), distances 2e-5 abs, gradients: max(3e-5, 5x the
+           reference's own float32-vs-float64 deviation on the same input) -- SURVEY.md 8c.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import closed_form
+
+pytestmark = pytest.mark.gpu
+
+G1 = load_golden("g1_airm_self.npz")
+G1X = load_golden("g1x_airm_cross.npz")
+G2 = load_golden("g2_fisher_rao.npz")
+G1_CASES = [tuple(c) for c in G1["cases"]]
+G1X_CASES = [tuple(c) for c in G1X["cases"]]
+G2_CASES = [tuple(c) for c in G2["cases"]]
+MAXM = 33  # largest m with a native kernel in this round
+
+DEV = "cuda:0"
+
+
+def _fused(S, scale=1.0, sqrt_mode=True):
+    from sqfa_amd import _native, distances
+    C = S.shape[0]
+    P = C * (C - 1) // 2
+    S = S.clone().requires_grad_(True)
+    loss, flags = _native.PairwiseLoss.apply(S, scale, distances.EPSILON, sqrt_mode, -1.0 / P, (0, 1), None)
+    loss.backward()
+    return loss.detach(), S.grad, flags
+
+
+def _tols(dtype, key=None, gkey="grad"):
+    if dtype == torch.float64:
+        return dict(loss=1e-11, dist=1e-10, grad=1e-8)
+    ref_dev = 0.0
+    if key is not None:
+        ref_dev = rel_err(G1[f"{key}_{gkey}_f32"], G1[f"{key}_{gkey}_f64"])
+    return dict(loss=1e-5, dist=2e-5, grad=max(3e-5, 5 * ref_dev))
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("C,m", [c for c in G1_CASES if c[1] <= MAXM])
+def test_fused_loss_and_grad_vs_golden(C, m, dtype):
+    key = f"C{C}_m{m}"
+    S = torch.tensor(G1[f"{key}_S"], dtype=dtype, device=DEV)
+    tol = _tols(dtype, key)
+    loss, grad, flags = _fused(S)
+    assert flags.tolist() == [0, 0]
+    ref = float(G1[f"{key}_loss_f64"])
+    assert abs(loss.item() - ref) <= tol["loss"] * abs(ref)
+    assert rel_err(grad.cpu(), G1[f"{key}_grad_f64"]) <= tol["grad"]
+    # squared-distance variant
+    tol = _tols(dtype, key, "grad_sq")
+    loss, grad, flags = _fused(S, sqrt_mode=False)
+    ref = float(G1[f"{key}_loss_sq_f64"])
+    assert abs(loss.item() - ref) <= tol["loss"] * abs(ref)
+    assert rel_err(grad.cpu(), G1[f"{key}_grad_sq_f64"]) <= tol["grad"]
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("C,m", [c for c in G1_CASES if c[1] <= MAXM])
+def test_distance_matrix_wrappers_vs_golden(C, m, dtype):
+    from sqfa_amd import distances
+    key = f"C{C}_m{m}"
+    S = torch.tensor(G1[f"{key}_S"], dtype=dtype, device=DEV, requires_grad=True)
+    tol = _tols(dtype, key)
+    D = distances.affine_invariant(S, S)
+    assert D.shape == (C, C)
+    assert np.abs(D.detach().cpu().numpy() - G1[f"{key}_d_f64"]).max() <= tol["dist"] * max(1.0, G1[f"{key}_d_f64"].max())
+    # generic autograd path: same loss as the reference closure, through the (C,C) matrix
+    r, c = torch.tril_indices(C, C, offset=-1)
+    loss = -D[r.to(DEV), c.to(DEV)].mean()
+    (g,) = torch.autograd.grad(loss, S)
+    assert rel_err(g.cpu(), G1[f"{key}_grad_f64"]) <= tol["grad"]
+    Dsq = distances.affine_invariant_sq(S.detach(), S.detach())
+    scale = max(1.0, G1[f"{key}_dsq_f64"].max())
+    assert np.abs(Dsq.cpu().numpy() - G1[f"{key}_dsq_f64"]).max() <= 5 * tol["dist"] * scale
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("nA,nB,m", G1X_CASES)
+def test_cross_batches_vs_golden(nA, nB, m, dtype):
+    from sqfa_amd import distances, linalg
+    key = f"A{nA}_B{nB}_m{m}"
+    A = torch.tensor(G1X[f"{key}_A"], dtype=dtype, device=DEV, requires_grad=True)
+    B = torch.tensor(G1X[f"{key}_B"], dtype=dtype, device=DEV, requires_grad=True)
+    W = torch.tensor(G1X[f"{key}_W"], dtype=dtype, device=DEV)
+    f64 = dtype == torch.float64
+    lam = linalg.generalized_eigenvalues(A.detach(), B.detach())
+    assert tuple(lam.shape) == G1X[f"{key}_lam_f64"].shape
+    assert rel_err(lam.cpu(), G1X[f"{key}_lam_f64"]) <= (1e-10 if f64 else 2e-5)
+    for name, fn in (("d", distances.affine_invariant), ("dsq", distances.affine_invariant_sq)):
+        D = fn(A, B)
+        assert tuple(D.shape) == G1X[f"{key}_{name}_f64"].shape   # the reference's squeeze rules
+        assert rel_err(D.detach().cpu(), G1X[f"{key}_{name}_f64"]) <= (1e-10 if f64 else 2e-5)
+        loss = (W.reshape(D.shape) * D).sum()
+        gA, gB = torch.autograd.grad(loss, (A, B))
+        dev_ref = max(rel_err(G1X[f"{key}_gA_{name}_f32"], G1X[f"{key}_gA_{name}_f64"]),
+                      rel_err(G1X[f"{key}_gB_{name}_f32"], G1X[f"{key}_gB_{name}_f64"]))
+        gtol = 1e-8 if f64 else max(3e-5, 5 * dev_ref)
+        assert rel_err(gA.cpu(), G1X[f"{key}_gA_{name}_f64"]) <= gtol
+        assert rel_err(gB.cpu(), G1X[f"{key}_gB_{name}_f64"]) <= gtol
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("C,K", [c for c in G2_CASES if c[1] + 1 <= MAXM])
+def test_fisher_rao_vs_golden(C, K, dtype):
+    from sqfa_amd import distances
+    key = f"C{C}_K{K}"
+    mu = torch.tensor(G2[f"{key}_mu"], dtype=dtype, device=DEV, requires_grad=True)
+    cov = torch.tensor(G2[f"{key}_cov"], dtype=dtype, device=DEV, requires_grad=True)
+    st = {"means": mu, "covariances": cov}
+    f64 = dtype == torch.float64
+    emb = distances.embed_gaussian(st)
+    assert rel_err(emb.detach().cpu(), G2[f"{key}_emb_f64"]) <= (1e-14 if f64 else 1e-6)
+    for tag, fn in (("fr", distances.fisher_rao_lower_bound), ("frsq", distances.fisher_rao_lower_bound_sq)):
+        D = fn(st, st)
+        assert rel_err(D.detach().cpu(), G2[f"{key}_{tag}_f64"]) <= (1e-10 if f64 else 2e-5)
+        r, c = torch.tril_indices(C, C, offset=-1)
+        loss = -D[r.to(DEV), c.to(DEV)].mean()
+        gmu, gcov = torch.autograd.grad(loss, (mu, cov))
+        sfx = "" if tag == "fr" else "_sq"
+        dev_ref = max(rel_err(G2[f"{key}_gmu{sfx}_f32"], G2[f"{key}_gmu{sfx}_f64"]),
+                      rel_err(G2[f"{key}_gcov{sfx}_f32"], G2[f"{key}_gcov{sfx}_f64"]))
+        gtol = 1e-8 if f64 else max(3e-5, 5 * dev_ref)
+        assert rel_err(gmu.cpu(), G2[f"{key}_gmu{sfx}_f64"]) <= gtol
+        assert rel_err(gcov.cpu(), G2[f"{key}_gcov{sfx}_f64"]) <= gtol
+
+
+def test_nonfinite_flag_and_error_message():
+    from sqfa_amd import _native, distances
+    from sqfa_amd._optim import raise_on_flags
+    S = torch.tensor(G1["C8_m4_S"], dtype=torch.float32, device=DEV)
+    S[3] = -S[3]  # not SPD -> NaN Cholesky -> NaN distances for the 7 pairs touching class 3
+    loss, flags = _native.PairwiseLoss.apply(S, 1.0, distances.EPSILON, True, -1.0 / 28, (0, 1), None)
+    assert flags.tolist()[0] == 7
+    with pytest.raises(ValueError, match="NaN"):
+        raise_on_flags(flags)
+
+
+def test_run_to_run_bitwise_reproducible():
+    S = torch.tensor(G1["C37_m16_S"], dtype=torch.float32, device=DEV)
+    l1, g1, _ = _fused(S)
+    l2, g2, _ = _fused(S)
+    assert torch.equal(l1, l2) and torch.equal(g1, g2)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_tile_shards_sum_to_the_whole(world):
+    from sqfa_amd import _native, distances
+    S = torch.tensor(G1["C37_m16_S"], dtype=torch.float64, device=DEV)
+    P = 37 * 36 // 2
+    full_l, full_g, _ = _fused(S)
+    acc_l, acc_g = 0.0, torch.zeros_like(S)
+    for rank in range(world):
+        out = _native.hip_pair_backend(S, None, scale=1.0, eps=distances.EPSILON, sqrt_mode=True, weights=None,
+                                       uniform_weight=-1.0 / P, shard=(rank, world), want_loss=True,
+                                       want_grad=True, want_dist=False, want_eig=False)
+        acc_l += out["loss"].item()
+        acc_g += out["gradA"]
+    assert abs(acc_l - full_l.item()) < 1e-12
+    assert rel_err(acc_g.cpu(), full_g.cpu()) < 1e-12
+
+
+@pytest.mark.parametrize("C,m,dtype", [(300, 16, torch.float32), (200, 17, torch.float32), (120, 32, torch.float32),
+                                       (90, 33, torch.float32), (150, 8, torch.float32), (100, 16, torch.float64)])
+def test_medium_sizes_vs_closed_form_oracle(C, m, dtype):
+    """Sizes the numpy oracle still finishes in seconds; exercises many tiles and ragged edges."""
+    rng = np.random.default_rng(C * 100 + m)
+    X = rng.standard_normal((C, 3 * m, m))
+    S = np.einsum("cnm,cnk->cmk", X, X) / (3 * m) + 0.02 * np.eye(m)
+    loss_ref, grad_ref, _ = closed_form.closure_loss_and_grad(S)
+    loss, grad, flags = _fused(torch.tensor(S, dtype=dtype, device=DEV))
+    assert flags.tolist() == [0, 0]
+    f64 = dtype == torch.float64
+    assert abs(loss.item() - loss_ref) <= (1e-11 if f64 else 1e-5) * abs(loss_ref)
+    assert rel_err(grad.cpu(), grad_ref) <= (1e-8 if f64 else 5e-5)
+
+
+def test_full_size_properties_c3():
+    """BASELINE config c3 (C=1000, m=16): size-independent properties instead of an oracle run:
+    congruence invariance d(G S G^T) = d(S), inversion invariance, gradient sums."""
+    torch.manual_seed(0)
+    C, m = 1000, 16
+    X = torch.randn(C, 4 * m, m, dtype=torch.float64)
+    S = (X.transpose(1, 2) @ X / (4 * m) + 0.05 * torch.eye(m, dtype=torch.float64)).to(DEV)
+    Gm = (torch.randn(m, m, dtype=torch.float64) + 3 * torch.eye(m, dtype=torch.float64)).to(DEV)
+    l0, g0, flags = _fused(S)
+    assert flags.tolist() == [0, 0]
+    l1, _, _ = _fused(Gm @ S @ Gm.T)
+    l2, _, _ = _fused(torch.linalg.inv(S))
+    assert abs(l1.item() - l0.item()) < 1e-9 * abs(l0.item())
+    assert abs(l2.item() - l0.item()) < 1e-9 * abs(l0.item())
+    # Euler: the loss is invariant to S -> t S (all classes), so <grad, S> = 0
+    assert abs((g0 * S).sum().item()) < 1e-10
+    # float32 run agrees with the float64 run
+    l32, g32, _ = _fused(S.float())
+    assert abs(l32.item() - l0.item()) < 1e-5 * abs(l0.item())
+    assert rel_err(g32.cpu(), g0.cpu()) < 5e-5
