@@ -121,8 +121,11 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v) { return group_
 // Jacobi rotation parameters for "my" column (squared norm no) against a partner column
 // (squared norm nr) with inner product gam.  Symmetric formulation: both owners evaluate
 // this with their own (no, nr) and apply  x' = cs*x - sn*x_partner,  no' = no - tl*gam.
+// The two owners must choose opposite signs of t; zeta = (nr-no)/(2 gam) does that by itself
+// except when the norms are EXACTLY equal (zeta = +0 on both sides): `tie` (+1 on one owner,
+// -1 on the other) breaks that tie antisymmetrically.
 template <typename T>
-__device__ __forceinline__ void rot_params(T no, T nr, T gam, T tol2, T& cs, T& sn, T& tl, bool& big) {
+__device__ __forceinline__ void rot_params(T no, T nr, T gam, T tol2, T tie, T& cs, T& sn, T& tl, bool& big) {
   using R = Real<T>;
   const T ab = no * nr;
   const T g2 = gam * gam;
@@ -130,7 +133,7 @@ __device__ __forceinline__ void rot_params(T no, T nr, T gam, T tol2, T& cs, T& 
   big = big || (g2 > R::kEarly2 * ab);
   const T zeta = (nr - no) * (T(0.5) * R::rcp(gam));
   const T w = R::sqrt_(R::fma_(zeta, zeta, T(1)));
-  T t = R::copysign_(R::rcp(R::abs_(zeta) + w), zeta);
+  T t = R::copysign_(R::rcp(R::abs_(zeta) + w), zeta == T(0) ? tie : zeta);
   const T c = R::rsq(R::fma_(t, t, T(1)));
   tl = rot ? t : T(0);
   cs = rot ? c : T(1);
@@ -151,6 +154,8 @@ template <typename T, int MR, int CPL, int S>
 __device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], int s, T tol2, bool& big) {
   using R = Real<T>;
   constexpr int TP2 = pow2ceil(CPL);
+  const int lane_id = (int)(threadIdx.x & 63);
+  const T tie = ((lane_id ^ s) > lane_id) ? T(1) : T(-1);
 #pragma unroll
   for (int t = 0; t < TP2; ++t) {
 #pragma unroll
@@ -166,7 +171,7 @@ __device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], int 
       const T nr1 = lane_xor<S>(nrm[cp], s);
       T cs1, sn1, tl1;
       if (cp == c) {
-        rot_params(nrm[c], nr1, gam1, tol2, cs1, sn1, tl1, big);
+        rot_params(nrm[c], nr1, gam1, tol2, tie, cs1, sn1, tl1, big);
 #pragma unroll
         for (int r = 0; r < MR; ++r) x[c][r] = cs1 * x[c][r] - sn1 * rv[r];
         nrm[c] -= tl1 * gam1;
@@ -174,8 +179,8 @@ __device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], int 
         const T gam2 = lane_xor<S>(gam1, s);
         const T nr2 = lane_xor<S>(nrm[c], s);
         T cs2, sn2, tl2;
-        rot_params(nrm[c], nr1, gam1, tol2, cs1, sn1, tl1, big);
-        rot_params(nrm[cp], nr2, gam2, tol2, cs2, sn2, tl2, big);
+        rot_params(nrm[c], nr1, gam1, tol2, tie, cs1, sn1, tl1, big);
+        rot_params(nrm[cp], nr2, gam2, tol2, tie, cs2, sn2, tl2, big);
 #pragma unroll
         for (int r = 0; r < MR; ++r) x[c][r] = cs1 * x[c][r] - sn1 * rv[r];
         const T ics2 = R::fma_(tl2, tl2, T(1)) * cs2;  // 1/cs2 (cs2 = rsq(1+tl2^2); both 1 when not rotating)
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
 #pragma unroll
           for (int r = 0; r < MR; ++r) gam = R::fma_(x[c1][r], x[c2][r], gam);
           T cs, sn, tl;
-          rot_params(nrm[c1], nrm[c2], gam, tol2, cs, sn, tl, big);
+          rot_params(nrm[c1], nrm[c2], gam, tol2, T(1), cs, sn, tl, big);
 #pragma unroll
           for (int r = 0; r < MR; ++r) {
             const T xp = x[c1][r], xq = x[c2][r];

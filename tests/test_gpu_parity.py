@@ -204,3 +204,25 @@ def test_full_size_properties_c3():
     l32, g32, _ = _fused(S.float())
     assert abs(l32.item() - l0.item()) < 1e-5 * abs(l0.item())
     assert rel_err(g32.cpu(), g0.cpu()) < 5e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("m", [4, 16, 17, 32])
+def test_exactly_degenerate_pairs(m, dtype):
+    """A_i == B_j gives X = I up to rounding: exactly equal column norms with non-zero inner
+    products, where the two owners of a rotation must still pick opposite signs."""
+    from sqfa_amd import distances
+    S = torch.tensor(G1["C10_m16_S"][:, :m, :m] if m <= 16 else G1[f"C{ {17: 9, 32: 6}[m] }_m{m}_S"],
+                     dtype=dtype, device=DEV)
+    D = distances.affine_invariant_sq(S, S.clone())
+    assert torch.diagonal(D).abs().max().item() < (1e-20 if dtype == torch.float64 else 1e-9)
+    D2 = distances.affine_invariant_sq(S, S)
+    off = ~torch.eye(S.shape[0], dtype=torch.bool, device=DEV)
+    assert torch.allclose(D[off], D2[off], rtol=1e-5 if dtype == torch.float32 else 1e-12)
+    # identical classes and scalar multiples of the identity
+    I = torch.eye(m, dtype=dtype, device=DEV)
+    T = torch.stack([I, 2 * I, I, 0.5 * I])
+    Dt = distances.affine_invariant_sq(T, T)
+    expect = m * torch.log(torch.tensor([[1, .5, 1, 2], [2, 1, 2, 4], [1, .5, 1, 2], [.5, .25, .5, 1.]],
+                                        dtype=dtype, device=DEV)) ** 2
+    assert torch.allclose(Dt, expect, atol=1e-5)
