@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Benchmark of the SQFA hot path on MI355X: SPD pairwise-distance loss+grad evaluations/s.
+
+One *step* = one M1 evaluation: given the C feature scatters S (C,m,m)
+resident in HBM, produce the scalar loss -mean_{i>j} d(S_i,S_j) and dloss/dS.
+Workload (default) = BASELINE.json configs[2] "c3": C=1000 classes, n_dim=784, n_filters=16,
+float32, SecondMomentsSQFA (m=16), synthetic Gaussians of SURVEY.md 8(d).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+With N > 1 every rank holds the same S, evaluates the tile shard (bi+bj) % N == rank and the
+partial loss / flags / gradient are summed with one RCCL all-reduce per step ("strong" scaling:
+the problem is fixed, `value` is whole-job evaluations per second).
+
+Rank 0 prints ONE JSON line.  Extra objects: "roofline" (pair tile kernel, measured live with
+HIP events on the launch stream) and "cpu_baseline" (the oracle's torch-CPU port of the
+reference op sequence, timed on the host on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector == f32 MFMA dense peak
+HBM_PEAK_GBS = 8000.0
+
+WORKLOADS = {
+    # name: (C, D, K, model)   model: "smsqfa" -> m=K, "sqfa" -> m=K+1 (Calvo-Oller embedding, scale 1/2)
+    "c2": (100, 784, 8, "smsqfa"),
+    "c3": (1000, 784, 16, "smsqfa"),
+    "c3-sqfa": (1000, 784, 16, "sqfa"),
+    "c4": (1000, 2048, 32, "smsqfa"),
+    "c5": (100, 3072, 16, "sqfa"),
+}
+
+
+def make_feature_scatters(C, D, K, model, device, dtype=torch.float32, seed=1234, feature_noise=0.01):
+    """Synthetic classes of SURVEY.md 8(d): Sigma_c = A_c A_c^T + 0.05 I, A_c ~ N(0,1)^{D x R}/sqrt(R),
+    R = min(D,128); mu_c ~ 0.1 N(0,1); filters F ~ N(0,1)^{K x D} (seed 7) on the sphere.
+    Returns the kernel input S (C,m,m): F Psi_c F^T + noise*I (smsqfa) or the Calvo-Oller
+    embedding of (F mu_c, F Sigma_c F^T + noise*I) (sqfa).  The (C,D,D) tensor is never formed:
+    F Sigma_c F^T = (F A_c)(F A_c)^T + 0.05 F F^T."""
+    R = min(D, 128)
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    F = torch.randn(K, D, generator=torch.Generator(device="cpu").manual_seed(7), dtype=torch.float64)
+    F = F / F.norm(dim=1, keepdim=True)
+    F = F.to(device)
+    eye = torch.eye(K, dtype=torch.float64, device=device)
+    cov = torch.empty(C, K, K, dtype=torch.float64, device=device)
+    fmu = torch.empty(C, K, dtype=torch.float64, device=device)
+    chunk = 50
+    for c0 in range(0, C, chunk):
+        n = min(chunk, C - c0)
+        A = torch.randn(n, D, R, generator=gen, dtype=torch.float32).to(device, torch.float64) / R ** 0.5
+        mu = 0.1 * torch.randn(n, D, generator=gen, dtype=torch.float32).to(device, torch.float64)
+        FA = F[None] @ A
+        cov[c0:c0 + n] = FA @ FA.transpose(1, 2) + 0.05 * (F @ F.T)[None] + feature_noise * eye[None]
+        fmu[c0:c0 + n] = mu @ F.T
+    if model == "smsqfa":
+        S = cov + fmu[:, :, None] * fmu[:, None, :]
+        scale = 1.0
+    else:
+        from sqfa_amd.distances import embed_gaussian
+        S = embed_gaussian({"means": fmu, "covariances": cov})
+        scale = 0.5
+    return S.to(dtype).contiguous(), scale
+
+
+def cpu_baseline(S_cpu, scale, C_full, seconds_budget=25.0):
+    """Time the oracle's torch-CPU port of the reference algorithm (all ordered pairs, eigh
+    whitening, batched eigvalsh, autograd) on the first C_s classes of the same workload."""
+    from oracle import reference_path
+    threads = torch.get_num_threads()
+    C_s = min(C_full, 300)
+    sample = S_cpu[:C_s].clone()
+    t0 = time.perf_counter()
+    reference_path.pairwise_loss_and_grad(sample[:60], scale=scale)  # warm-up (MKL init)
+    t_warm = time.perf_counter() - t0
+    times = []
+    while sum(times) < seconds_budget and len(times) < 3:
+        t0 = time.perf_counter()
+        reference_path.pairwise_loss_and_grad(sample, scale=scale)
+        times.append(time.perf_counter() - t0)
+    t = min(times)
+    # the reference evaluates all C^2 ordered pairs: cost ~ C^2
+    est_full = t * (C_full / C_s) ** 2
+    return {
+        "value": 1.0 / est_full,
+        "unit": "evals/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"oracle/reference_path.py (torch CPU, {threads} threads) on the first {C_s} of {C_full} classes "
+                  f"({C_s * C_s} ordered pairs): {t:.2f} s/eval best of {len(times)}; scaled by (C/C_s)^2 to the full workload "
+                  f"(= {est_full:.1f} s/eval); warm-up {t_warm:.1f} s",
+        "sample_seconds_per_eval": t,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    from sqfa_amd import _lib, _native
+    from sqfa_amd.parallel import PairShard
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+        shard = PairShard()
+    else:
+        shard = PairShard(rank=0, world_size=1)
+
+    C, D, K, model = WORKLOADS[args.workload]
+    dtype = torch.float32 if args.dtype == "f32" else torch.float64
+    S, scale = make_feature_scatters(C, D, K, model, device, dtype)
+    m = S.shape[1]
+    P = C * (C - 1) // 2
+    weight = -1.0 / P
+    lib = _lib.load()
+
+    def step():
+        out = _native.hip_pair_backend(S, None, scale=scale, eps=_native.EPSILON, sqrt_mode=True, weights=None,
+                                       uniform_weight=weight, shard=shard.shard, want_loss=True, want_grad=True,
+                                       want_dist=False, want_eig=False)
+        return shard.reduce(out["loss"], out["nonfinite"], out["gradA"])
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss, flags, grad = step()
+    fence()
+    lib.sqfa_airm_profile(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, flags, grad = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    lib.sqfa_airm_profile(0)
+    import ctypes
+    ms_total, launches = ctypes.c_double(0), ctypes.c_int(0)
+    lib.sqfa_airm_profile_read(ctypes.byref(ms_total), ctypes.byref(launches))
+    kernel_ms = ms_total.value / max(launches.value, 1)
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+        kmax = torch.tensor([kernel_ms], dtype=torch.float64, device=device)
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+        kernel_ms = kmax.item()
+    assert flags.tolist() == [0, 0], f"non-finite distances: {flags.tolist()}"
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        evals_per_s = args.steps / elapsed
+        flops_eval = 8.0 * C * (C - 1) * m ** 3          # 16 m^3 per unordered pair
+        flops_launch = flops_eval / world                # each rank's launch covers 1/world of the tiles
+        achieved_tf = flops_launch / (kernel_ms * 1e-3) / 1e12
+        esz = 4 if dtype == torch.float32 else 8
+        bytes_eval = esz * (2 * C * m * m + 1)
+        result = {
+            "metric": "SPD pairwise-distance loss+grad evals/sec",
+            "value": evals_per_s,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: C={C} classes, n_dim={D}, n_filters={K}, {model} (m={m}), "
+                            f"{P} unordered pairs per eval, inputs resident in HBM",
+                "parallelism": f"pair-tile shard over {world} GPU(s) + 1 all-reduce of [loss,flags,grad] per eval",
+            },
+            "pairs_per_s": evals_per_s * P,
+            "loss": loss.item(),
+            "roofline": {
+                "bound": "mfma",
+                "achieved": achieved_tf,
+                "peak": FP32_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved_tf / FP32_PEAK_TFLOPS,
+                "traffic": None,
+                "kernel": "pair_tile_kernel",
+                "kernel_ms": kernel_ms,
+                "algorithmic_flops_per_launch": flops_launch,
+                "note": "FP32 compute-bound kernel: the f32 VALU peak equals the f32 MFMA dense peak (157.3 TF); "
+                        "algorithmic flops = 16*m^3 per unordered pair (SURVEY.md 8d). Algorithmic HBM traffic is "
+                        f"{bytes_eval / 1e6:.2f} MB per eval = {bytes_eval / (kernel_ms * 1e-3) / 1e9:.1f} GB/s, "
+                        f"{bytes_eval / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS * 100:.3f}% of the 8 TB/s HBM roofline",
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(S.detach().cpu(), scale, C)
+            result["speedup_vs_cpu_baseline"] = evals_per_s / result["cpu_baseline"]["value"]
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

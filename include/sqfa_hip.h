@@ -103,9 +103,17 @@ int sqfa_airm_pairwise(const void *A, int nA, const void *B, int nB, int m, int 
                        void *dist_out, void *eig_out, int *nonfinite_out,
                        void *workspace, size_t workspace_bytes, void *stream);
 
-/* Debug/introspection: average Jacobi sweeps per wave-round of the last call is
- * written to sweeps_out[0] (float, device) if a buffer was registered; pass NULL to disable. */
+/* Introspection (benchmarks / development; not needed by a reference-side binding).
+ *
+ * sqfa_airm_set_sweep_counter: register a device buffer of two uint64 {sum of Jacobi sweeps,
+ *   number of wave rounds}; the tile kernel adds to it atomically.  NULL disables.
+ * sqfa_airm_profile(1): every following sqfa_airm_pairwise call brackets its pair tile kernel
+ *   with hipEvents recorded on the caller's stream.  sqfa_airm_profile_read synchronises on
+ *   those events, returns the summed kernel time [ms] and the number of launches, and
+ *   releases them (call it outside any timed region). */
 int sqfa_airm_set_sweep_counter(unsigned long long *device_counter2);
+int sqfa_airm_profile(int enable);
+int sqfa_airm_profile_read(double *tile_kernel_ms_total, int *launches);
 
 #ifdef __cplusplus
 }

@@ -3,6 +3,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <vector>
+
 #include "../../include/sqfa_hip.h"
 #include "configs.hpp"
 #include "pair_kernel.hpp"
@@ -39,6 +41,11 @@ static int max_dim() {
 
 static thread_local char g_last_error[256] = "";
 static unsigned long long* g_sweep_counter = nullptr;
+
+// optional per-launch timing of the pair tile kernel with HIP events on the caller's stream
+struct EventPair { hipEvent_t a, b; };
+static bool g_profile = false;
+static std::vector<EventPair> g_events;
 
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -224,6 +231,29 @@ int sqfa_airm_set_sweep_counter(unsigned long long* device_counter2) {
   return SQFA_OK;
 }
 
+int sqfa_airm_profile(int enable) {
+  g_profile = enable != 0;
+  return SQFA_OK;
+}
+
+int sqfa_airm_profile_read(double* tile_kernel_ms_total, int* launches) {
+  double total = 0.0;
+  int n = 0;
+  for (auto& ev : g_events) {
+    float ms = 0.f;
+    if (hipEventSynchronize(ev.b) == hipSuccess && hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
+      total += ms;
+      ++n;
+    }
+    hipEventDestroy(ev.a);
+    hipEventDestroy(ev.b);
+  }
+  g_events.clear();
+  if (tile_kernel_ms_total) *tile_kernel_ms_total = total;
+  if (launches) *launches = n;
+  return SQFA_OK;
+}
+
 int sqfa_airm_tiling(int nA, int nB, int m, int dtype, int* tile_i, int* tile_j, int* n_tiles_i,
                      int* n_tiles_j, int* padded_m) {
   if (nA < 1 || nB < 0 || m < 1 || (dtype != SQFA_F32 && dtype != SQFA_F64)) return SQFA_ERR_BAD_ARGUMENT;
@@ -318,7 +348,17 @@ int sqfa_airm_pairwise(const void* A, int nA, const void* B, int nB, int m, int 
   if (e != hipSuccess) return fail(SQFA_ERR_LAUNCH, "cholesky_kernel", e);
 
   // K1: pair tiles
+  EventPair ev{};
+  if (g_profile) {
+    hipEventCreate(&ev.a);
+    hipEventCreate(&ev.b);
+    hipEventRecord(ev.a, stream);
+  }
   e = g.launch(p, stream);
+  if (g_profile) {
+    hipEventRecord(ev.b, stream);
+    g_events.push_back(ev);
+  }
   if (e != hipSuccess) return fail(SQFA_ERR_LAUNCH, "pair_tile_kernel", e);
 
   // K2: slab reduction
