@@ -1,0 +1,69 @@
+"""N > 1 path on the CPU: two gloo ranks, each evaluating its tile shard (oracle pair backend)
+followed by PairShard's single all-reduce.  Checks that the reduced loss / gradient equal the
+unsharded result, are bitwise identical on both ranks, and that a sharded fit walks the same
+trajectory as the single-process fit."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_golden
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import model_cases as mc
+        from oracle_backend import oracle_pair_backend
+        from sqfa_amd import _native, distances
+        from sqfa_amd.parallel import PairShard
+        _native.set_pair_backend(oracle_pair_backend)
+        G1 = load_golden("g1_airm_self.npz")
+        S = torch.tensor(G1["C37_m16_S"])
+        P = 37 * 36 // 2
+        shard = PairShard()
+        assert shard.shard == (rank, world)
+        Sg = S.clone().requires_grad_(True)
+        loss, flags = _native.PairwiseLoss.apply(Sg, 1.0, distances.EPSILON, True, -1.0 / P, shard.shard, shard.reduce)
+        loss.backward()
+        # sharded fit
+        stats = mc.fit_stats("syn", torch.float64, torch.device("cpu"))
+        model = mc.make_model("sqfa", 50, 2, 1e-3, "sphere", torch.float64, "cpu")
+        model.fit_pca(data_statistics=stats)
+        model.pair_shard = shard
+        fl, _ = model.fit(data_statistics=stats, max_epochs=3, show_progress=False, return_loss=True)
+        q.put((rank, loss.item(), Sg.grad.numpy(), flags.tolist(), fl.numpy(), model.filters.detach().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_pair_shard_matches_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    G1 = load_golden("g1_airm_self.npz")
+    G4 = load_golden("g4_fit.npz")
+    (_, l0, g0, f0, fl0, F0), (_, l1, g1, f1, fl1, F1) = results
+    assert l0 == l1 and np.array_equal(g0, g1) and np.array_equal(F0, F1)      # identical on both ranks
+    assert f0 == [0, 0] and f1 == [0, 0]
+    assert abs(l0 - float(G1["C37_m16_loss_f64"])) < 1e-12
+    assert np.linalg.norm(g0 - G1["C37_m16_grad_f64"]) < 1e-9 * np.linalg.norm(g0)
+    assert np.abs(fl0 - G4["syn_sqfa_K2_e3_loss"]).max() < 1e-6
+    assert np.linalg.norm(F0 - G4["syn_sqfa_K2_e3_filters"]) < 1e-7 * np.linalg.norm(F0)

@@ -1,0 +1,206 @@
+"""CPU tests of the host side (model shell, fitting loop, statistics, constraints, torch-only
+distance operators) with the float64 ORACLE installed as pair backend, against the goldens
+captured from the reference (G3 closure, G4 fit trajectories, G5 quirks) and the
+reference's error contract (its tests/test_training.py)."""
+import numpy as np
+import pytest
+import torch
+
+import model_cases as mc
+from conftest import rel_err
+from oracle_backend import oracle_pair_backend
+
+
+@pytest.fixture(autouse=True)
+def _oracle_backend():
+    from sqfa_amd import _native
+    _native.set_pair_backend(oracle_pair_backend)
+    yield
+    _native.set_pair_backend(None)
+
+
+CPU = torch.device("cpu")
+
+
+@pytest.mark.parametrize("key", mc.G3_KEYS)
+def test_closure_matches_reference(key):
+    mc.check_closure(key, torch.float64, CPU, tol_loss=1e-10, tol_grad=1e-7, tol_dist=1e-9)
+
+
+@pytest.mark.parametrize("dname", ["rot", "syn"])
+@pytest.mark.parametrize("model_name", ["smsqfa", "sqfa"])
+@pytest.mark.parametrize("K,noise", [(2, 1e-3), (4, 1e-2)])
+@pytest.mark.parametrize("epochs", [1, 3])
+def test_short_fit_trajectories(dname, model_name, K, noise, epochs):
+    # losses come back as a float32 tensor (default dtype, like the reference) -> 1e-6.
+    # rot/K=4 sits on the flat orbit F -> G F of the AIRM loss (SURVEY.md 7 "hard parts"; the
+    # reference's own float32 run diverges there): only its losses are compared.
+    flat = dname == "rot" and K == 4 and epochs > 1
+    mc.check_fit(dname, model_name, K, noise, epochs, CPU, tol_loss=1e-4 if flat else 1e-6,
+                 tol_filters=1.0 if flat else 1e-7)
+
+
+@pytest.mark.parametrize("model_name", ["smsqfa", "sqfa"])
+def test_full_fit_to_convergence_rot(model_name):
+    # stopping rule, epoch count and learned filters of a converged float64 fit
+    mc.check_fit("rot", model_name, 2, 1e-3, 300, CPU, tol_loss=1e-6, tol_filters=1e-5)
+
+
+def test_pairwise_fit_syn():
+    mc.check_fit("syn", "smsqfa", 4, 1e-2, 300, CPU, tol_loss=1e-6, tol_filters=1e-4, pairwise=True)
+
+
+# ---------------------------------------------------------------- error contract (reference tests/test_training.py)
+def _rot_cov():
+    return torch.tensor(mc.G4["rotated_cov"], dtype=torch.float32)
+
+
+def test_sqfa_rejects_tensor_statistics():
+    import sqfa_amd
+    model = sqfa_amd.model.SQFA(n_dim=8, feature_noise=0.001, n_filters=2)
+    with pytest.raises(TypeError):
+        sqfa_amd._optim.fitting_loop(model=model, data_statistics=_rot_cov(), max_epochs=2, show_progress=False)
+    with pytest.raises(TypeError):
+        model.fit(data_statistics=_rot_cov(), max_epochs=2, show_progress=False)
+    with pytest.raises(TypeError):
+        model.get_class_distances(_rot_cov())
+
+
+def test_fit_argument_errors():
+    import sqfa_amd
+    m3 = sqfa_amd.model.SecondMomentsSQFA(n_dim=8, feature_noise=0.001, n_filters=3)
+    with pytest.raises(ValueError, match="even"):
+        m3.fit(data_statistics=_rot_cov(), pairwise=True, max_epochs=2, show_progress=False)
+    m2 = sqfa_amd.model.SecondMomentsSQFA(n_dim=8, n_filters=2)
+    with pytest.raises(ValueError):
+        m2.fit(max_epochs=2)
+    with pytest.raises(ValueError):
+        m2.fit_pca()
+    with pytest.raises(TypeError):
+        m2.fit(data_statistics=[1, 2, 3], max_epochs=2)
+    with pytest.raises(ValueError):
+        m2.fit(data_statistics={"means": torch.zeros(5, 8)}, max_epochs=2)
+    with pytest.raises(ValueError):
+        sqfa_amd.model.SecondMomentsSQFA(n_dim=3, n_filters=5)
+
+
+@pytest.mark.parametrize("model_name", ["smsqfa", "sqfa"])
+@pytest.mark.parametrize("n_filters", [1, 2, 4])
+@pytest.mark.parametrize("pairwise", [False, True])
+def test_fit_runs_float32(model_name, n_filters, pairwise):
+    import sqfa_amd
+    torch.manual_seed(1)
+    cov = _rot_cov()
+    stats = {"means": torch.zeros(5, 8), "covariances": cov}
+    cls = sqfa_amd.model.SQFA if model_name == "sqfa" else sqfa_amd.model.SecondMomentsSQFA
+    model = cls(n_dim=8, feature_noise=0.01, n_filters=n_filters)
+    if pairwise and n_filters % 2:
+        with pytest.raises(ValueError):
+            model.fit(data_statistics=stats, pairwise=True, max_epochs=3, show_progress=False)
+        return
+    loss, t = model.fit(data_statistics=stats, pairwise=pairwise, max_epochs=4, show_progress=False, return_loss=True)
+    assert torch.isfinite(loss).all() and model.filters.shape == (n_filters, 8)
+    assert sorted(model.state_dict()) == ["noise_mat", "parametrizations.filters.original"]
+    assert model.transform(torch.randn(7, 8)).shape == (7, n_filters)
+    assert model.transform_scatters(cov).shape == (5, n_filters, n_filters)
+
+
+def test_orthogonal_constraint_keeps_filters_orthonormal():
+    import sqfa_amd
+    torch.manual_seed(3)
+    stats = mc.fit_stats("syn", torch.float64, CPU)
+    with mc.default_dtype(torch.float64):
+        model = sqfa_amd.model.SQFA(n_dim=50, feature_noise=0.01, n_filters=3, constraint="orthogonal").double()
+    loss, _ = model.fit(data_statistics=stats, max_epochs=3, show_progress=False, return_loss=True)
+    F = model.filters.detach()
+    assert torch.allclose(F @ F.T, torch.eye(3, dtype=torch.float64), atol=1e-10)
+    assert loss[-1] <= loss[0]
+
+
+def test_fit_from_points_and_nan_guard():
+    import sqfa_amd
+    g5 = mc.G5
+    X = torch.tensor(g5["pts_X"], dtype=torch.float32)
+    y = torch.tensor(g5["pts_y"])
+    model = sqfa_amd.model.SQFA(n_dim=6, feature_noise=0.01, n_filters=2)
+    model.fit_pca(X=X)
+    assert rel_err(model.filters.detach(), sqfa_amd.statistics.pca(X, 2)) < 1e-6
+    loss, _ = model.fit(X=X, y=y, max_epochs=3, show_progress=False, return_loss=True)
+    assert torch.isfinite(loss).all()
+    bad = sqfa_amd.model.SecondMomentsSQFA(n_dim=6, feature_noise=0.0, n_filters=2)
+    S = torch.eye(6).repeat(4, 1, 1)
+    S[1] = -S[1]
+    with pytest.raises(ValueError, match="NaN"):
+        bad.fit(data_statistics=S, max_epochs=2, show_progress=False)
+
+
+# ---------------------------------------------------------------- statistics / linalg / other distances (G5)
+def test_statistics_match_reference():
+    from sqfa_amd import statistics
+    g5 = mc.G5
+    X = torch.tensor(g5["pts_X"])
+    y = torch.tensor(g5["pts_y"])
+    for est in ("empirical", "oas"):
+        st = statistics.class_statistics(X, y, estimator=est)
+        assert sorted(st) == ["covariances", "means", "second_moments"]
+        for k, v in st.items():
+            assert rel_err(v, g5[f"class_stats_{est}_{k}"]) < 1e-12
+    assert rel_err(statistics.pca(X, 3), g5["pca_X_K3"]) < 1e-10
+    assert rel_err(statistics.oas_covariance(X), g5["oas_cov"]) < 1e-12
+    assert rel_err(statistics.sample_covariance(X), g5["sample_cov"]) < 1e-12
+    rot = torch.tensor(g5["rotated_cov"])
+    for K in (1, 2, 4, 8):
+        assert rel_err(statistics.pca_from_scatter(rot, K), g5[f"pca_from_scatter_K{K}"]) < 1e-10
+    with pytest.raises(ValueError):
+        statistics.pca(X, 7)
+    with pytest.raises(ValueError):
+        statistics.pca_from_scatter(rot, 9)
+
+
+def test_linalg_helpers_and_shapes():
+    from sqfa_amd import distances, linalg
+    g5 = mc.G5
+    spd = torch.tensor(g5["spd"])
+    assert rel_err(linalg.spd_sqrt(spd), g5["spd_sqrt"]) < 1e-12
+    assert rel_err(linalg.spd_log(spd), g5["spd_log"]) < 1e-12
+    W = linalg.spd_inv_sqrt(spd)
+    assert rel_err(W @ spd @ W.transpose(1, 2), g5["spd_inv_sqrt_whitened"]) < 1e-10
+    gv, ge = linalg.generalized_eigenvectors(spd[:3], spd[1:4])
+    assert rel_err(gv.abs(), g5["gen_eigvec_abs"]) < 1e-8 and rel_err(ge, g5["gen_eigval"]) < 1e-10
+    for nA, nB, nd_d, nd_l in g5["squeeze_shapes"]:
+        A, B = spd[:nA], spd[:nB]
+        assert distances.affine_invariant_sq(A, B).dim() == nd_d
+        assert linalg.generalized_eigenvalues(A, B).dim() == nd_l
+    assert tuple(distances.affine_invariant_sq(spd[0], spd[:4]).shape) == tuple(g5["squeeze_2d_A"])
+    with pytest.raises(ValueError):
+        linalg.conjugate_matrix(spd, torch.ones(3))
+    F = torch.randn(2, 3, dtype=torch.float64)
+    assert linalg.conjugate_matrix(spd, F).shape == (4, 2, 2)
+    assert linalg.conjugate_matrix(spd[0], F).shape == (2, 2)
+    assert linalg.conjugate_matrix(spd, torch.stack([F, F])).shape == (4, 2, 2, 2)
+
+
+def test_other_distance_operators():
+    from sqfa_amd import distances
+    g5 = mc.G5
+    st = {"means": torch.tensor(g5["dist_mu"]), "covariances": torch.tensor(g5["dist_cov"])}
+    assert rel_err(distances.log_euclidean_sq(st["covariances"], st["covariances"]), g5["log_euclidean_sq"]) < 1e-10
+    assert rel_err(distances.log_euclidean(st["covariances"], st["covariances"]), g5["log_euclidean"]) < 1e-10
+    for name in ("bhattacharyya", "mahalanobis_sq", "mahalanobis", "hellinger", "fisher_rao_same_cov"):
+        assert rel_err(getattr(distances, name)(st, st), g5[name]) < 1e-9, name
+    assert sorted(distances.__all__) == sorted(
+        ["affine_invariant_sq", "affine_invariant", "log_euclidean_sq", "log_euclidean", "fisher_rao_lower_bound",
+         "fisher_rao_lower_bound_sq", "bhattacharyya", "mahalanobis_sq", "mahalanobis", "hellinger",
+         "fisher_rao_same_cov"])
+
+
+def test_custom_distance_fun_uses_generic_closure():
+    import sqfa_amd
+    from oracle import reference_path
+    cov = torch.tensor(mc.G4["rotated_cov"], dtype=torch.float64)
+    with mc.default_dtype(torch.float64):
+        model = sqfa_amd.model.SecondMomentsSQFA(n_dim=8, n_filters=2, feature_noise=1e-3,
+                                                 distance_fun=reference_path.affine_invariant).double()
+    assert model._fused_closure_loss(cov) is None
+    loss, _ = model.fit(data_statistics=cov, max_epochs=2, show_progress=False, return_loss=True)
+    assert torch.isfinite(loss).all()
