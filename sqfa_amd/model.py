@@ -180,7 +180,8 @@ class SecondMomentsSQFA(nn.Module):
             fresh = start_filters[done:done + 2]
             init = fresh.contiguous() if stage == 0 else torch.cat((learned, fresh))
             self._replace_filters(init, n_row_fixed=done)
-            self.register_buffer("noise_mat", (noise_level * torch.eye(done + 2)).to(start_filters.device))
+            self.register_buffer(
+                "noise_mat", noise_level * torch.eye(done + 2, dtype=noise_level.dtype, device=noise_level.device))
             stage_loss, stage_time = fitting_loop(model=self, data_statistics=data_statistics, **loop)
             # drop the FixedFilters layer again
             remove_parametrizations(self, "filters")

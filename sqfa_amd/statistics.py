@@ -58,8 +58,12 @@ def pca(points, n_components=None):
         n_components = min(n, d)
     if n_components > d:
         raise ValueError("n_components must be less than or equal to n_dim.")
-    _, vecs = torch.linalg.eigh(sample_covariance(points))
-    return vecs[:, d - n_components:].flip(1).T
+    cov = sample_covariance(points)
+    # One-off (D,D) eigh, run through LAPACK on the host like the reference: eigenvectors are
+    # only defined up to sign (and up to a rotation inside degenerate eigenspaces), and
+    # rocSOLVER makes different choices, which would start every fit from a different point.
+    _, vecs = torch.linalg.eigh(cov.cpu())
+    return vecs[:, d - n_components:].flip(1).T.to(cov.device)
 
 
 def pca_from_scatter(scatters, n_components=None):

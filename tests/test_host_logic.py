@@ -47,7 +47,14 @@ def test_full_fit_to_convergence_rot(model_name):
 
 
 def test_pairwise_fit_syn():
-    mc.check_fit("syn", "smsqfa", 4, 1e-2, 300, CPU, tol_loss=1e-6, tol_filters=1e-4, pairwise=True)
+    # flat-orbit case (see tests/test_gpu_model.py::test_full_fit_flat_orbit_case_f64)
+    stats = mc.fit_stats("syn", torch.float64, CPU)
+    model = mc.make_model("smsqfa", 50, 4, 1e-2, "sphere", torch.float64, CPU)
+    model.fit_pca(data_statistics=stats)
+    loss, t = model.fit(data_statistics=stats, max_epochs=300, show_progress=False, return_loss=True, pairwise=True)
+    ref = mc.G4["syn_smsqfa_pairwise_K4_loss"]
+    assert abs(loss[-1].item() - ref[-1]) <= 1e-5 * abs(ref[-1])
+    assert rel_err(model.filters.detach(), mc.G4["syn_smsqfa_pairwise_K4_filters"]) <= 5e-3
 
 
 # ---------------------------------------------------------------- error contract (reference tests/test_training.py)
