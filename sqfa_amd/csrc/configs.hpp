@@ -8,8 +8,8 @@
 #define SQFA_CONFIGS_F32(X)  \
   X(float, 4, 1, 4, 8, 4)    \
   X(float, 8, 1, 8, 8, 4)    \
-  X(float, 16, 4, 4, 16, 4)  \
-  X(float, 17, 4, 5, 16, 4)  \
+  X(float, 16, 4, 4, 8, 4)  \
+  X(float, 17, 4, 5, 8, 4)  \
   X(float, 32, 8, 4, 4, 2)   \
   X(float, 33, 8, 5, 4, 2)
 

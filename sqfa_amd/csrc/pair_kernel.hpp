@@ -120,24 +120,32 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v) { return group_
 // ---------------------------------------------------------------------------------------
 // Jacobi rotation parameters for "my" column (squared norm no) against a partner column
 // (squared norm nr) with inner product gam.  Symmetric formulation: both owners evaluate
-// this with their own (no, nr) and apply  x' = cs*x - sn*x_partner,  no' = no - tl*gam.
+// this with their own (no, nr) and apply  x' = cs*x - sn*x_partner,  no' = no - tl*gam
+// (or, against an already rotated partner column, x' = ics*x - tl*x_partner_new).
 // The two owners must choose opposite signs of t; zeta = (nr-no)/(2 gam) does that by itself
 // except when the norms are EXACTLY equal (zeta = +0 on both sides): `tie` (+1 on one owner,
 // -1 on the other) breaks that tie antisymmetrically.
 template <typename T>
-__device__ __forceinline__ void rot_params(T no, T nr, T gam, T tol2, T tie, T& cs, T& sn, T& tl, bool& big) {
+__device__ __forceinline__ void rot_params(T no, T nr, T gam, T tol2, T tie, T& cs, T& ics, T& sn, T& tl, bool& big) {
+  // Half-angle form with two reciprocal square roots (the transcendental unit runs at a
+  // quarter of the FMA rate): with d = (nr-no)/2, h = sqrt(d^2 + gam^2):
+  //   cos 2th = |d|/h, sin 2th = sign(d) gam/h  (|th| <= pi/4)
+  //   cs = cos th = sqrt((1 + cos 2th)/2),  sn = sin th = sin 2th / (2 cs),  tl = sn/cs, ics = 1/cs
   using R = Real<T>;
   const T ab = no * nr;
   const T g2 = gam * gam;
   const bool rot = g2 > tol2 * ab;
   big = big || (g2 > R::kEarly2 * ab);
-  const T zeta = (nr - no) * (T(0.5) * R::rcp(gam));
-  const T w = R::sqrt_(R::fma_(zeta, zeta, T(1)));
-  T t = R::copysign_(R::rcp(R::abs_(zeta) + w), zeta == T(0) ? tie : zeta);
-  const T c = R::rsq(R::fma_(t, t, T(1)));
-  tl = rot ? t : T(0);
-  cs = rot ? c : T(1);
-  sn = tl * cs;
+  const T d = T(0.5) * (nr - no);
+  const T rh = R::rsq(R::fma_(d, d, g2));
+  const T u = R::fma_(T(0.5) * R::abs_(d), rh, T(0.5));
+  const T rc = R::rsq(u);
+  const T sgn = d == T(0) ? tie : d;
+  const T s_ = R::copysign_(T(0.5) * R::abs_(gam * rh * rc), sgn) * R::copysign_(T(1), gam);
+  cs = rot ? u * rc : T(1);
+  ics = rot ? rc : T(1);
+  sn = rot ? s_ : T(0);
+  tl = sn * ics;
 }
 
 // one tournament round against the lane group member (lane ^ s): every column slot c of
@@ -169,26 +177,21 @@ __device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], int 
 #pragma unroll
       for (int r = 0; r < MR; ++r) gam1 = R::fma_(x[c][r], rv[r], gam1);
       const T nr1 = lane_xor<S>(nrm[cp], s);
-      T cs1, sn1, tl1;
-      if (cp == c) {
-        rot_params(nrm[c], nr1, gam1, tol2, tie, cs1, sn1, tl1, big);
+      T cs1, ics1, sn1, tl1;
+      rot_params(nrm[c], nr1, gam1, tol2, tie, cs1, ics1, sn1, tl1, big);
 #pragma unroll
-        for (int r = 0; r < MR; ++r) x[c][r] = cs1 * x[c][r] - sn1 * rv[r];
-        nrm[c] -= tl1 * gam1;
-      } else {
+      for (int r = 0; r < MR; ++r) x[c][r] = cs1 * x[c][r] - sn1 * rv[r];
+      nrm[c] -= tl1 * gam1;
+      if (cp != c) {
+        // my slot cp meets the partner's slot c: the partner has just evaluated exactly that
+        // rotation from its side (as ITS slot-c rotation); its parameters are mine mirrored.
         const T gam2 = lane_xor<S>(gam1, s);
-        const T nr2 = lane_xor<S>(nrm[c], s);
-        T cs2, sn2, tl2;
-        rot_params(nrm[c], nr1, gam1, tol2, tie, cs1, sn1, tl1, big);
-        rot_params(nrm[cp], nr2, gam2, tol2, tie, cs2, sn2, tl2, big);
-#pragma unroll
-        for (int r = 0; r < MR; ++r) x[c][r] = cs1 * x[c][r] - sn1 * rv[r];
-        const T ics2 = R::fma_(tl2, tl2, T(1)) * cs2;  // 1/cs2 (cs2 = rsq(1+tl2^2); both 1 when not rotating)
+        const T ics2 = lane_xor<S>(ics1, s);
+        const T tl2 = -lane_xor<S>(tl1, s);
 #pragma unroll
         for (int r = 0; r < MR; ++r) rv[r] = lane_xor<S>(x[c][r], s);  // partner's slot c, rotated
 #pragma unroll
         for (int r = 0; r < MR; ++r) x[cp][r] = ics2 * x[cp][r] - tl2 * rv[r];
-        nrm[c] -= tl1 * gam1;
         nrm[cp] -= tl2 * gam2;
       }
     }
@@ -220,7 +223,7 @@ struct PairCfg {
   static constexpr int MAX_SWEEPS = 30;
   // register budget: waves per SIMD the kernel is compiled for (256-thread blocks)
   static constexpr int XREGS = CPL * MR * (int)(sizeof(T) / 4);
-  static constexpr int MIN_WAVES = XREGS <= 72 ? 3 : (XREGS <= 170 ? 2 : 1);
+  static constexpr int MIN_WAVES = XREGS <= 72 ? 4 : (XREGS <= 170 ? 2 : 1);
   static_assert(G * CPL >= MR, "not enough column slots");
   static_assert(TJ % WAVES == 0, "TJ must be a multiple of the wave count");
 };
@@ -235,7 +238,6 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
   constexpr int WAVES = Cfg::WAVES, TRI = Cfg::TRI, TRIP = Cfg::TRIP, NT = Cfg::THREADS;
 
   __shared__ T s_ga[WAVES * TI * TRIP];  // per-wave private A-side accumulators (lower triangles)
-  __shared__ T s_gb[TJ * TRIP];          // B-side sums, one owner wave per j
   __shared__ T s_li[WAVES * MR * MR];    // L_j^-1 of the B class each wave is working on
   __shared__ T s_red[WAVES];
   __shared__ int s_redi[2 * WAVES];
@@ -253,7 +255,6 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
 
   if (p.want_grad) {
     for (int k = tid; k < WAVES * TI * TRIP; k += NT) s_ga[k] = T(0);
-    for (int k = tid; k < TJ * TRIP; k += NT) s_gb[k] = T(0);
   }
   __syncthreads();
 
@@ -269,7 +270,13 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
   for (int jj = wave; jj < TJ; jj += WAVES) {
     const int j = j0 + jj;  // wave-uniform
     const bool valid = (i < p.nA) && (j < p.nB) && (!p.self_mode || i > j);
-    if (!__any(valid)) continue;
+    if (!__any(valid)) {
+      if (p.want_grad) {  // nothing to add for this B class, but the slab entry must be defined
+        T* gbz = static_cast<T*>(p.slab_grad) + ((size_t)tile * (TI + TJ) + TI + jj) * TRI;
+        for (int k = lane; k < TRI; k += 64) gbz[k] = T(0);
+      }
+      continue;
+    }
     const int jc = __builtin_amdgcn_readfirstlane(j < p.nB ? j : p.nB - 1);
     T* li = s_li + wave * (MR * MR);
     {
@@ -325,8 +332,8 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
           T gam = T(0);
 #pragma unroll
           for (int r = 0; r < MR; ++r) gam = R::fma_(x[c1][r], x[c2][r], gam);
-          T cs, sn, tl;
-          rot_params(nrm[c1], nrm[c2], gam, tol2, T(1), cs, sn, tl, big);
+          T cs, ics, sn, tl;
+          rot_params(nrm[c1], nrm[c2], gam, tol2, T(1), cs, ics, sn, tl, big);
 #pragma unroll
           for (int r = 0; r < MR; ++r) {
             const T xp = x[c1][r], xq = x[c2][r];
@@ -429,7 +436,8 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
       // group (A side) / of the wave (B side) holds the same value and performs the same
       // LDS update on the same address, so no lane predicate is needed.
       T* ga = s_ga + (size_t)(wave * TI + prob) * TRIP;
-      T* gb = s_gb + (size_t)jj * TRIP;
+      // B side: this wave is the only writer of (tile, jj); every lane stores the same value
+      T* gb = static_cast<T*>(p.slab_grad) + ((size_t)tile * (TI + TJ) + TI + jj) * TRI;
 #pragma unroll
       for (int r = 0; r < MR; ++r) {
         T sa[CPL], sb[CPL];
@@ -488,10 +496,6 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
 #pragma unroll
       for (int wv = 0; wv < WAVES; ++wv) acc += s_ga[(size_t)(wv * TI + pi) * TRIP + idx];
       slab[k] = acc;
-    }
-    for (int k = tid; k < TJ * TRI; k += NT) {
-      const int pj = k / TRI, idx = k % TRI;
-      slab[TI * TRI + k] = s_gb[(size_t)pj * TRIP + idx];
     }
   }
 }
