@@ -57,7 +57,10 @@ __host__ __device__ constexpr int tri_index(int r, int c) { return r * (r + 1) /
 template <typename T> struct Real;
 template <> struct Real<float> {
   static constexpr float kEps = 1.1920929e-07f;
-  static constexpr float kEarly2 = 1.0e-7f;  // (3.2e-4)^2: sweep in which every |cos| stays below -> last sweep
+#ifndef SQFA_EARLY2_F32
+#define SQFA_EARLY2_F32 1.0e-7f
+#endif
+  static constexpr float kEarly2 = SQFA_EARLY2_F32;  // a sweep in which every cos^2 between columns stays below this is the last one
   static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
   static __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
   static __device__ __forceinline__ float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
@@ -102,6 +105,27 @@ template <int S, typename T> __device__ __forceinline__ T lane_xor(T v, int s) {
   else if constexpr (S == 3) return dpp_mov<0x1B>(v);
   else if constexpr (S == 0) return __shfl_xor(v, s, 64);
   else return __shfl_xor(v, S, 64);
+}
+
+// Same, for the r-th element of a column: DPP moves cost two VALU issue slots on gfx950
+// (tools/ubench/valu_rate.hip), ds_swizzle runs on the otherwise idle LDS crossbar (~2.3
+// cycles per wave-op per CU, tools/ubench/swizzle_rate.hip).  Every SQFA_SWZ_MOD-th row goes
+// through the crossbar so both pipes share the cross-lane traffic (0 = DPP only).
+#ifndef SQFA_SWZ_MOD
+#define SQFA_SWZ_MOD 2
+#endif
+template <int S> __device__ __forceinline__ float swizzle_xor(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (S << 10) | 0x1F));
+}
+template <int S> __device__ __forceinline__ double swizzle_xor(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  return __hiloint2double(__builtin_amdgcn_ds_swizzle(hi, (S << 10) | 0x1F), __builtin_amdgcn_ds_swizzle(lo, (S << 10) | 0x1F));
+}
+template <int S, typename T> __device__ __forceinline__ T lane_xor_row(T v, int s, int r) {
+  if constexpr (S >= 1 && S <= 3 && SQFA_SWZ_MOD > 0) {
+    if (r % SQFA_SWZ_MOD == 0) return swizzle_xor<S>(v);
+  }
+  return lane_xor<S>(v, s);
 }
 
 // sum over the G lanes of a lane group (every lane gets the total)
@@ -172,7 +196,7 @@ __device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], int 
       if (cp < c || cp >= CPL) continue;  // resolved at compile time after unrolling
       T rv[MR];
 #pragma unroll
-      for (int r = 0; r < MR; ++r) rv[r] = lane_xor<S>(x[cp][r], s);  // partner's slot cp
+      for (int r = 0; r < MR; ++r) rv[r] = lane_xor_row<S>(x[cp][r], s, r);  // partner's slot cp
       T gam1 = T(0);
 #pragma unroll
       for (int r = 0; r < MR; ++r) gam1 = R::fma_(x[c][r], rv[r], gam1);
@@ -189,7 +213,7 @@ __device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], int 
         const T ics2 = lane_xor<S>(ics1, s);
         const T tl2 = -lane_xor<S>(tl1, s);
 #pragma unroll
-        for (int r = 0; r < MR; ++r) rv[r] = lane_xor<S>(x[c][r], s);  // partner's slot c, rotated
+        for (int r = 0; r < MR; ++r) rv[r] = lane_xor_row<S>(x[c][r], s, r);  // partner's slot c, rotated
 #pragma unroll
         for (int r = 0; r < MR; ++r) x[cp][r] = ics2 * x[cp][r] - tl2 * rv[r];
         nrm[cp] -= tl2 * gam2;
@@ -207,6 +231,81 @@ __device__ __forceinline__ void cross_rounds_static(T (&x)[CPL][MR], T (&nrm)[CP
 }
 
 // ---------------------------------------------------------------------------------------
+// Transposing tree reduction.  Every lane holds a value for each of 2^LEVEL consecutive
+// indices [BASE, BASE + 2^LEVEL); the sum over the 2^LEVEL lanes of an aligned lane block is
+// wanted for each index.  A butterfly would cost LEVEL cross-lane adds PER INDEX and leave
+// the result replicated; here, at distance d = 2^(LEVEL-1) a lane keeps the half of the
+// indices selected by its own bit and hands the other half to its partner, so the work
+// halves per level (~2 cross-lane adds per index in total) and lane l of the block ends with
+// the finished sum of index BASE + l -- ready for a conflict-free LDS update / coalesced store.
+template <int D, typename T> __device__ __forceinline__ T xor_fetch(T v) {
+  if constexpr (D == 1) return dpp_mov<0xB1>(v);
+  else if constexpr (D == 2) return dpp_mov<0x4E>(v);
+  else if constexpr (D < 32) return swizzle_xor<D>(v);
+  else return __shfl_xor(v, D, 64);
+}
+
+__host__ __device__ constexpr int tri_row(int idx) {
+  int r = 0;
+  while ((r + 1) * (r + 2) / 2 <= idx) ++r;
+  return r;
+}
+
+// lower-triangle entry IDX of  sum_c coef[c] * x[c] x[c]^T  over this lane's column slots
+template <typename T, int MR, int CPL>
+struct OuterProduct {
+  const T (&x)[CPL][MR];
+  const T (&coef)[CPL];
+  template <int IDX> __device__ __forceinline__ T get() const {
+    if constexpr (IDX >= MR * (MR + 1) / 2) {
+      return T(0);
+    } else {
+      constexpr int r = tri_row(IDX), cc = IDX - r * (r + 1) / 2;
+      T acc = T(0);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) acc = Real<T>::fma_(coef[c] * x[c][r], x[c][cc], acc);
+      return acc;
+    }
+  }
+};
+
+template <int LEVEL, int BASE, typename T, typename P>
+__device__ __forceinline__ T tree_reduce(const P& prod, int lane) {
+  if constexpr (LEVEL == 0) {
+    return prod.template get<BASE>();
+  } else {
+    constexpr int H = 1 << (LEVEL - 1);
+    const T a = tree_reduce<LEVEL - 1, BASE, T>(prod, lane);
+    const T b = tree_reduce<LEVEL - 1, BASE + H, T>(prod, lane);
+    const bool upper = (lane & H) != 0;
+    const T keep = upper ? b : a;
+    const T send = upper ? a : b;
+    return keep + xor_fetch<H>(send);
+  }
+}
+
+template <int LEVEL, int I, int N, int TRI, typename T, typename P, typename F>
+__device__ __forceinline__ void tree_reduce_blocks(const P& prod, int lane, F&& sink) {
+  if constexpr (I < N) {
+    constexpr int W = 1 << LEVEL;
+    const T v = tree_reduce<LEVEL, I * W, T>(prod, lane);
+    const int idx = I * W + (lane & (W - 1));
+    if constexpr ((I + 1) * W <= TRI) {
+      sink(idx, v);
+    } else {
+      if (idx < TRI) sink(idx, v);
+    }
+    tree_reduce_blocks<LEVEL, I + 1, N, TRI, T>(prod, lane, sink);
+  }
+}
+
+__host__ __device__ constexpr int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+// ---------------------------------------------------------------------------------------
 template <typename T, int MR_, int G_, int CPL_, int TJ_, int WAVES_>
 struct PairCfg {
   using type = T;
@@ -220,7 +319,10 @@ struct PairCfg {
   static constexpr int TI = PPW;     // A classes per tile
   static constexpr int TRI = MR * (MR + 1) / 2;
   static constexpr int TRIP = TRI | 1;  // odd LDS stride between matrices
-  static constexpr int MAX_SWEEPS = 30;
+#ifndef SQFA_MAX_SWEEPS
+#define SQFA_MAX_SWEEPS 30
+#endif
+  static constexpr int MAX_SWEEPS = SQFA_MAX_SWEEPS;
   // register budget: waves per SIMD the kernel is compiled for (256-thread blocks)
   static constexpr int XREGS = CPL * MR * (int)(sizeof(T) / 4);
   static constexpr int MIN_WAVES = XREGS <= 72 ? 4 : (XREGS <= 170 ? 2 : 1);
@@ -432,33 +534,19 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
 #pragma unroll
         for (int c = 0; c < CPL; ++c) x[c][r] = acc[c];
       }
-      // rank-one sums, lower triangle, row by row.  After the reductions every lane of a
-      // group (A side) / of the wave (B side) holds the same value and performs the same
-      // LDS update on the same address, so no lane predicate is needed.
-      T* ga = s_ga + (size_t)(wave * TI + prob) * TRIP;
-      // B side: this wave is the only writer of (tile, jj); every lane stores the same value
-      T* gb = static_cast<T*>(p.slab_grad) + ((size_t)tile * (TI + TJ) + TI + jj) * TRI;
-#pragma unroll
-      for (int r = 0; r < MR; ++r) {
-        T sa[CPL], sb[CPL];
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-          sa[c] = coefA[c] * x[c][r];
-          sb[c] = coefB[c] * x[c][r];
-        }
-#pragma unroll
-        for (int cc = 0; cc <= r; ++cc) {
-          T pa = T(0), pb = T(0);
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) {
-            pa = R::fma_(sa[c], x[c][cc], pa);
-            pb = R::fma_(sb[c], x[c][cc], pb);
-          }
-          pa = group_sum<G>(pa);
-          pb = wave_sum(pb);
-          ga[tri_index(r, cc)] += pa;
-          gb[tri_index(r, cc)] = pb;
-        }
+      // rank-one sums (lower triangles) with transposing tree reductions:
+      //   A side: over the G lanes of the pair; lane g finishes entries idx = G*i + g and adds
+      //           them to this wave's private LDS accumulator of class i
+      //   B side: over all 64 lanes (every pair of the wave shares j); lane l finishes entries
+      //           idx = 64*i + l and stores them to the slab (this wave is the only writer)
+      {
+        T* ga = s_ga + (size_t)(wave * TI + prob) * TRIP;
+        const OuterProduct<T, MR, CPL> prodA{x, coefA};
+        constexpr int LG = ilog2(G);
+        tree_reduce_blocks<LG, 0, (TRI + G - 1) / G, TRI, T>(prodA, lane, [&](int idx, T v) { ga[idx] += v; });
+        T* gb = static_cast<T*>(p.slab_grad) + ((size_t)tile * (TI + TJ) + TI + jj) * TRI;
+        const OuterProduct<T, MR, CPL> prodB{x, coefB};
+        tree_reduce_blocks<6, 0, (TRI + 63) / 64, TRI, T>(prodB, lane, [&](int idx, T v) { gb[idx] = v; });
       }
     }
   }

@@ -68,41 +68,55 @@ static WorkspaceLayout layout(int nA, int nBeff, const Geometry& g, size_t esz, 
 }
 
 // ---- K0: per-class Cholesky factor and its inverse (always evaluated in double) ----------
-// One wave per class.  LT[c][col*MR + k] = L[k][col];  Linv[c][r*MR + k] = (L^-1)[r][k].
-// Both are padded to MR x MR with an identity block.  A non-SPD input produces NaNs,
-// which surface as non-finite distances (nonfinite_out), never as a fault.
+// One 256-thread workgroup per class, matrix in LDS.  LT[c][col*MR + k] = L[k][col];
+// Linv[c][r*MR + k] = (L^-1)[r][k].  Both are padded to MR x MR with an identity block.
+// A non-SPD input produces NaNs, which surface as non-finite distances (nonfinite_out),
+// never as a fault.
+//   Cholesky: right-looking, all (r,c) entries of the trailing block updated in parallel
+//   per pivot column (one LDS round trip per entry and pivot instead of a serial row loop).
+//   Inverse: X = L^-1 row by row; row r needs rows < r, columns are independent; the inner
+//   sum runs over k in parallel chunks of 4 lanes per column.
 template <typename T>
-__global__ __launch_bounds__(64) void cholesky_kernel(const T* __restrict__ S, int m, int MR,
-                                                      T* __restrict__ LT, T* __restrict__ Linv) {
+__global__ __launch_bounds__(256) void cholesky_kernel(const T* __restrict__ S, int m, int MR,
+                                                       T* __restrict__ LT, T* __restrict__ Linv) {
   __shared__ double a[64][65];
   __shared__ double b[64][65];
   const int c = blockIdx.x, t = threadIdx.x;
   const T* s = S + (size_t)c * m * m;
-  for (int idx = t; idx < m * m; idx += 64) a[idx / m][idx % m] = (double)s[idx];
+  for (int idx = t; idx < m * m; idx += 256) {
+    a[idx / m][idx % m] = (double)s[idx];
+    b[idx / m][idx % m] = 0.0;
+  }
   __syncthreads();
   for (int k = 0; k < m; ++k) {
     const double sd = sqrt(a[k][k]);
     __syncthreads();
-    if (t == k) a[k][k] = sd;
-    if (t > k && t < m) a[t][k] /= sd;
+    for (int r = k + t; r < m; r += 256) a[r][k] = (r == k) ? sd : a[r][k] / sd;
     __syncthreads();
-    if (t > k && t < m) {
-      const double ltk = a[t][k];
-      for (int c2 = k + 1; c2 <= t; ++c2) a[t][c2] -= ltk * a[c2][k];
+    // trailing update of the lower triangle: entries (r, c2) with k < c2 <= r < m
+    const int n = m - k - 1;
+    for (int e = t; e < n * n; e += 256) {
+      const int r = k + 1 + e / n, c2 = k + 1 + e % n;
+      if (c2 <= r) a[r][c2] -= a[r][k] * a[c2][k];
     }
     __syncthreads();
   }
-  if (t < m) {  // column t of L^-1 by forward substitution
-    b[t][t] = 1.0 / a[t][t];
-    for (int r = t + 1; r < m; ++r) {
+  // inverse: thread group of 4 lanes per column col (64 columns x 4 = 256 threads)
+  {
+    const int col = t >> 2, part = t & 3;
+    for (int r = 0; r < m; ++r) {
       double acc = 0.0;
-      for (int k = t; k < r; ++k) acc += a[r][k] * b[k][t];
-      b[r][t] = -acc / a[r][r];
+      if (col < r) {
+        for (int k = col + part; k < r; k += 4) acc += a[r][k] * b[k][col];
+      }
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      if (part == 0 && col <= r && col < m) b[r][col] = ((col == r ? 1.0 : 0.0) - acc) / a[r][r];
+      __syncthreads();
     }
   }
-  __syncthreads();
   const size_t base = (size_t)c * MR * MR;
-  for (int idx = t; idx < MR * MR; idx += 64) {
+  for (int idx = t; idx < MR * MR; idx += 256) {
     const int r = idx / MR, k = idx % MR;
     if (LT != nullptr) {  // here r = column of L, k = row of L
       double v = (r < m && k < m) ? (k >= r ? a[k][r] : 0.0) : (r == k ? 1.0 : 0.0);
@@ -117,19 +131,20 @@ __global__ __launch_bounds__(64) void cholesky_kernel(const T* __restrict__ S, i
 
 // ---- K2: fixed-order reduction of the tile slabs ------------------------------------------
 __device__ inline bool tile_processed(const PairParams& p, int bi, int bj, int TI, int TJ) {
-  if ((bi + bj) % p.shard_count != p.shard_index) return false;
+  if (p.shard_count > 1 && (bi + bj) % p.shard_count != p.shard_index) return false;
   if (p.self_mode && (bi * TI + TI - 1 <= bj * TJ)) return false;
   return true;
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void finalize_kernel(const PairParams p, int TI, int TJ, int MR,
+__global__ __launch_bounds__(512) void finalize_kernel(const PairParams p, int TI, int TJ, int MR,
                                                        T* __restrict__ gradA, T* __restrict__ gradB,
                                                        T* __restrict__ loss_out, int* __restrict__ nonfinite_out) {
   const int tid = threadIdx.x;
   const int TRI = MR * (MR + 1) / 2;
   const int n_cls = p.nA + (p.self_mode ? 0 : p.nB);
   const int b = blockIdx.x;
+  __shared__ T s_part[8 * 600];
   if (b < n_cls) {
     if (!p.want_grad) return;
     const bool a_side = b < p.nA;
@@ -138,21 +153,33 @@ __global__ __launch_bounds__(256) void finalize_kernel(const PairParams p, int T
     if (out == nullptr) return;
     const T* slab = static_cast<const T*>(p.slab_grad);
     const size_t tile_stride = (size_t)(TI + TJ) * TRI;
-    for (int idx = tid; idx < TRI; idx += 256) {
+    // NG thread groups each sum every NG-th contributing tile (a fixed subsequence), then the
+    // NG partial sums are combined in group order: short dependent chains, bitwise reproducible.
+    int NG = 512 / TRI;
+    NG = NG < 1 ? 1 : (NG > 8 ? 8 : NG);
+    const int n_a = a_side ? p.nbj : 0;                       // tiles (bi, *) holding this class as A
+    const int n_b = (!a_side || p.self_mode) ? p.nbi : 0;     // tiles (*, bj) holding it as B
+    const int bi_a = c / TI, pi = c % TI, bj_b = c / TJ, pj = c % TJ;
+    for (int e = tid; e < NG * TRI; e += 512) {
+      const int grp = e / TRI, idx = e % TRI;
+      T acc = T(0);
+      for (int q = grp; q < n_a + n_b; q += NG) {
+        if (q < n_a) {
+          if (tile_processed(p, bi_a, q, TI, TJ)) acc += slab[(size_t)(bi_a * p.nbj + q) * tile_stride + (size_t)pi * TRI + idx];
+        } else {
+          const int bi = q - n_a;
+          if (tile_processed(p, bi, bj_b, TI, TJ)) acc += slab[(size_t)(bi * p.nbj + bj_b) * tile_stride + (size_t)(TI + pj) * TRI + idx];
+        }
+      }
+      s_part[grp * 600 + idx] = acc;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < TRI; idx += 512) {
+      T acc = T(0);
+      for (int g2 = 0; g2 < NG; ++g2) acc += s_part[g2 * 600 + idx];
       int r = 0;
       while ((r + 1) * (r + 2) / 2 <= idx) ++r;
       const int cc = idx - r * (r + 1) / 2;
-      T acc = T(0);
-      if (a_side) {
-        const int bi = c / TI, pi = c % TI;
-        for (int bj = 0; bj < p.nbj; ++bj)
-          if (tile_processed(p, bi, bj, TI, TJ)) acc += slab[(size_t)(bi * p.nbj + bj) * tile_stride + (size_t)pi * TRI + idx];
-      }
-      if (!a_side || p.self_mode) {
-        const int bj = c / TJ, pj = c % TJ;
-        for (int bi = 0; bi < p.nbi; ++bi)
-          if (tile_processed(p, bi, bj, TI, TJ)) acc += slab[(size_t)(bi * p.nbj + bj) * tile_stride + (size_t)(TI + pj) * TRI + idx];
-      }
       if (r < p.m && cc < p.m) {
         out[(size_t)c * p.m * p.m + (size_t)r * p.m + cc] = acc;
         out[(size_t)c * p.m * p.m + (size_t)cc * p.m + r] = acc;
@@ -161,13 +188,13 @@ __global__ __launch_bounds__(256) void finalize_kernel(const PairParams p, int T
     return;
   }
   // last block: loss, flag, diagonals
-  __shared__ double s_l[256];
-  __shared__ int s_f[256];
-  __shared__ int s_f2[256];
+  __shared__ double s_l[512];
+  __shared__ int s_f[512];
+  __shared__ int s_f2[512];
   double l = 0.0;
   int f = 0, f2 = 0;
   const int ntiles = p.nbi * p.nbj;
-  for (int tix = tid; tix < ntiles; tix += 256) {
+  for (int tix = tid; tix < ntiles; tix += 512) {
     const int bi = tix / p.nbj, bj = tix % p.nbj;
     if (tile_processed(p, bi, bj, TI, TJ)) {
       l += (double)static_cast<const T*>(p.slab_loss)[tix];
@@ -179,7 +206,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const PairParams p, int T
   s_f[tid] = f;
   s_f2[tid] = f2;
   __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {
+  for (int st = 256; st > 0; st >>= 1) {
     if (tid < st) {
       s_l[tid] += s_l[tid + st];
       s_f[tid] += s_f[tid + st];
@@ -198,11 +225,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(const PairParams p, int T
     if (p.dist_out != nullptr) {
       T* D = static_cast<T*>(p.dist_out);
       const T dv = p.sqrt_mode ? (T)sqrt(p.eps) : T(0);
-      for (int c = tid; c < p.nA; c += 256) D[(size_t)c * p.nB + c] = dv;
+      for (int c = tid; c < p.nA; c += 512) D[(size_t)c * p.nB + c] = dv;
     }
     if (p.eig_out != nullptr) {
       T* E = static_cast<T*>(p.eig_out);
-      for (int k = tid; k < p.nA * p.m; k += 256) {
+      for (int k = tid; k < p.nA * p.m; k += 512) {
         const int c = k / p.m, q = k % p.m;
         E[((size_t)c * p.nB + c) * p.m + q] = T(1);
       }
@@ -329,19 +356,19 @@ int sqfa_airm_pairwise(const void* A, int nA, const void* B, int nB, int m, int 
     float* LT = reinterpret_cast<float*>(ws + w.off_lt);
     float* LI = reinterpret_cast<float*>(ws + w.off_linv);
     if (self_mode) {
-      hipLaunchKernelGGL(cholesky_kernel<float>, dim3(nA), dim3(64), 0, stream, static_cast<const float*>(A), m, g.MR, LT, LI);
+      hipLaunchKernelGGL(cholesky_kernel<float>, dim3(nA), dim3(256), 0, stream, static_cast<const float*>(A), m, g.MR, LT, LI);
     } else {
-      hipLaunchKernelGGL(cholesky_kernel<float>, dim3(nA), dim3(64), 0, stream, static_cast<const float*>(A), m, g.MR, LT, (float*)nullptr);
-      hipLaunchKernelGGL(cholesky_kernel<float>, dim3(nB), dim3(64), 0, stream, static_cast<const float*>(B), m, g.MR, (float*)nullptr, LI);
+      hipLaunchKernelGGL(cholesky_kernel<float>, dim3(nA), dim3(256), 0, stream, static_cast<const float*>(A), m, g.MR, LT, (float*)nullptr);
+      hipLaunchKernelGGL(cholesky_kernel<float>, dim3(nB), dim3(256), 0, stream, static_cast<const float*>(B), m, g.MR, (float*)nullptr, LI);
     }
   } else {
     double* LT = reinterpret_cast<double*>(ws + w.off_lt);
     double* LI = reinterpret_cast<double*>(ws + w.off_linv);
     if (self_mode) {
-      hipLaunchKernelGGL(cholesky_kernel<double>, dim3(nA), dim3(64), 0, stream, static_cast<const double*>(A), m, g.MR, LT, LI);
+      hipLaunchKernelGGL(cholesky_kernel<double>, dim3(nA), dim3(256), 0, stream, static_cast<const double*>(A), m, g.MR, LT, LI);
     } else {
-      hipLaunchKernelGGL(cholesky_kernel<double>, dim3(nA), dim3(64), 0, stream, static_cast<const double*>(A), m, g.MR, LT, (double*)nullptr);
-      hipLaunchKernelGGL(cholesky_kernel<double>, dim3(nB), dim3(64), 0, stream, static_cast<const double*>(B), m, g.MR, (double*)nullptr, LI);
+      hipLaunchKernelGGL(cholesky_kernel<double>, dim3(nA), dim3(256), 0, stream, static_cast<const double*>(A), m, g.MR, LT, (double*)nullptr);
+      hipLaunchKernelGGL(cholesky_kernel<double>, dim3(nB), dim3(256), 0, stream, static_cast<const double*>(B), m, g.MR, (double*)nullptr, LI);
     }
   }
   hipError_t e = hipGetLastError();
@@ -364,11 +391,11 @@ int sqfa_airm_pairwise(const void* A, int nA, const void* B, int nB, int m, int 
   // K2: slab reduction
   const int n_cls = nA + (self_mode ? 0 : nB);
   if (dtype == SQFA_F32) {
-    hipLaunchKernelGGL(finalize_kernel<float>, dim3(n_cls + 1), dim3(256), 0, stream, p, g.TI, g.TJ, g.MR,
+    hipLaunchKernelGGL(finalize_kernel<float>, dim3(n_cls + 1), dim3(512), 0, stream, p, g.TI, g.TJ, g.MR,
                        static_cast<float*>(gradA_out), static_cast<float*>(gradB_out),
                        static_cast<float*>(loss_out), nonfinite_out);
   } else {
-    hipLaunchKernelGGL(finalize_kernel<double>, dim3(n_cls + 1), dim3(256), 0, stream, p, g.TI, g.TJ, g.MR,
+    hipLaunchKernelGGL(finalize_kernel<double>, dim3(n_cls + 1), dim3(512), 0, stream, p, g.TI, g.TJ, g.MR,
                        static_cast<double*>(gradA_out), static_cast<double*>(gradB_out),
                        static_cast<double*>(loss_out), nonfinite_out);
   }
