@@ -11,7 +11,9 @@
   X(float, 16, 4, 4, 8, 4)  \
   X(float, 17, 4, 5, 8, 4)  \
   X(float, 32, 8, 4, 4, 2)   \
-  X(float, 33, 8, 5, 4, 2)
+  X(float, 33, 8, 5, 4, 2)   \
+  X(float, 48, 16, 3, 4, 2)  \
+  X(float, 64, 32, 2, 4, 2)
 
 #define SQFA_CONFIGS_F64(X)  \
   X(double, 4, 1, 4, 8, 4)   \
@@ -19,4 +21,6 @@
   X(double, 16, 8, 2, 8, 4)  \
   X(double, 17, 8, 3, 8, 4)  \
   X(double, 32, 16, 2, 4, 2) \
-  X(double, 33, 16, 3, 4, 2)
+  X(double, 33, 16, 3, 4, 2) \
+  X(double, 48, 32, 2, 4, 2) \
+  X(double, 64, 64, 1, 4, 2)

@@ -97,23 +97,6 @@ template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
   return __hiloint2double(dpp_mov_i<CTRL>(hi), dpp_mov_i<CTRL>(lo));
 }
 
-// value held by lane (lane ^ S).  S > 0: compile-time partner (DPP when S <= 3);
-// S == 0: runtime partner `s` (LDS crossbar).
-template <int S, typename T> __device__ __forceinline__ T lane_xor(T v, int s) {
-  if constexpr (S == 1) return dpp_mov<0xB1>(v);
-  else if constexpr (S == 2) return dpp_mov<0x4E>(v);
-  else if constexpr (S == 3) return dpp_mov<0x1B>(v);
-  else if constexpr (S == 0) return __shfl_xor(v, s, 64);
-  else return __shfl_xor(v, S, 64);
-}
-
-// Same, for the r-th element of a column: DPP moves cost two VALU issue slots on gfx950
-// (tools/ubench/valu_rate.hip), ds_swizzle runs on the otherwise idle LDS crossbar (~2.3
-// cycles per wave-op per CU, tools/ubench/swizzle_rate.hip).  Every SQFA_SWZ_MOD-th row goes
-// through the crossbar so both pipes share the cross-lane traffic (0 = DPP only).
-#ifndef SQFA_SWZ_MOD
-#define SQFA_SWZ_MOD 2
-#endif
 template <int S> __device__ __forceinline__ float swizzle_xor(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (S << 10) | 0x1F));
 }
@@ -121,6 +104,26 @@ template <int S> __device__ __forceinline__ double swizzle_xor(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   return __hiloint2double(__builtin_amdgcn_ds_swizzle(hi, (S << 10) | 0x1F), __builtin_amdgcn_ds_swizzle(lo, (S << 10) | 0x1F));
 }
+
+// value held by lane (lane ^ S).  S > 0: compile-time partner -- DPP quad_perm for S <= 3,
+// ds_swizzle (LDS crossbar, bit-mask mode) for 4 <= S < 32; S == 0: runtime partner `s`
+// through ds_bpermute (3x slower than ds_swizzle, tools/ubench/swizzle_rate.hip).
+template <int S, typename T> __device__ __forceinline__ T lane_xor(T v, int s) {
+  if constexpr (S == 1) return dpp_mov<0xB1>(v);
+  else if constexpr (S == 2) return dpp_mov<0x4E>(v);
+  else if constexpr (S == 3) return dpp_mov<0x1B>(v);
+  else if constexpr (S == 0) return __shfl_xor(v, s, 64);
+  else if constexpr (S < 32) return swizzle_xor<S>(v);
+  else return __shfl_xor(v, S, 64);
+}
+
+// Same, for the r-th element of a column: DPP moves cost two VALU issue slots on gfx950
+// (tools/ubench/valu_rate.hip), ds_swizzle runs on the otherwise idle LDS crossbar (~2.3
+// cycles per wave-op per CU).  Every SQFA_SWZ_MOD-th row goes through the crossbar so both
+// pipes share the cross-lane traffic (0 = DPP only).
+#ifndef SQFA_SWZ_MOD
+#define SQFA_SWZ_MOD 2
+#endif
 template <int S, typename T> __device__ __forceinline__ T lane_xor_row(T v, int s, int r) {
   if constexpr (S >= 1 && S <= 3 && SQFA_SWZ_MOD > 0) {
     if (r % SQFA_SWZ_MOD == 0) return swizzle_xor<S>(v);
@@ -323,6 +326,12 @@ struct PairCfg {
 #define SQFA_MAX_SWEEPS 30
 #endif
   static constexpr int MAX_SWEEPS = SQFA_MAX_SWEEPS;
+  // lane groups up to this size unroll the tournament rounds (compile-time partners: DPP / ds_swizzle);
+  // larger groups loop over the partner at run time (ds_bpermute)
+#ifndef SQFA_STATIC_G
+#define SQFA_STATIC_G 8
+#endif
+  static constexpr int STATIC_G = sizeof(T) == 4 ? SQFA_STATIC_G : 4;
   // register budget: waves per SIMD the kernel is compiled for (256-thread blocks)
   static constexpr int XREGS = CPL * MR * (int)(sizeof(T) / 4);
   static constexpr int MIN_WAVES = XREGS <= 72 ? 4 : (XREGS <= 170 ? 2 : 1);
@@ -447,9 +456,9 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
         }
       }
       // pairs across the lanes of my group
-      if constexpr (G > 1 && G <= 4) {
+      if constexpr (G > 1 && G <= Cfg::STATIC_G) {
         cross_rounds_static<T, MR, G, CPL, 1>(x, nrm, tol2, big);
-      } else if constexpr (G > 4) {
+      } else if constexpr (G > Cfg::STATIC_G) {
 #pragma unroll 1
         for (int s = 1; s < G; ++s) cross_round<T, MR, CPL, 0>(x, nrm, s, tol2, big);
       }

@@ -32,11 +32,11 @@ def test_identification():
     lib = _lib.load()
     assert lib.sqfa_hip_arch() == b"gfx950"
     assert lib.sqfa_hip_version() >= 1000
-    assert lib.sqfa_hip_max_dim() >= 33
+    assert lib.sqfa_hip_max_dim() >= 64
 
 
 @pytest.mark.parametrize("dtype", [_lib.SQFA_F32, _lib.SQFA_F64])
-@pytest.mark.parametrize("m", [1, 2, 4, 5, 8, 9, 16, 17, 32, 33])
+@pytest.mark.parametrize("m", [1, 2, 4, 5, 8, 9, 16, 17, 32, 33, 40, 48, 64])
 def test_tiling_and_workspace(m, dtype):
     lib = _lib.load()
     out = [ctypes.c_int() for _ in range(5)]

@@ -21,7 +21,7 @@ G2 = load_golden("g2_fisher_rao.npz")
 G1_CASES = [tuple(c) for c in G1["cases"]]
 G1X_CASES = [tuple(c) for c in G1X["cases"]]
 G2_CASES = [tuple(c) for c in G2["cases"]]
-MAXM = 33  # largest m with a native kernel in this round
+MAXM = 64  # largest m with a native kernel
 
 DEV = "cuda:0"
 
@@ -170,7 +170,9 @@ def test_tile_shards_sum_to_the_whole(world):
 
 
 @pytest.mark.parametrize("C,m,dtype", [(300, 16, torch.float32), (200, 17, torch.float32), (120, 32, torch.float32),
-                                       (90, 33, torch.float32), (150, 8, torch.float32), (100, 16, torch.float64)])
+                                       (90, 33, torch.float32), (150, 8, torch.float32), (100, 16, torch.float64),
+                                       (40, 40, torch.float32), (30, 48, torch.float64), (24, 64, torch.float32),
+                                       (12, 57, torch.float64), (70, 5, torch.float32), (33, 12, torch.float64)])
 def test_medium_sizes_vs_closed_form_oracle(C, m, dtype):
     """Sizes the numpy oracle still finishes in seconds; exercises many tiles and ragged edges."""
     rng = np.random.default_rng(C * 100 + m)
