@@ -74,6 +74,68 @@ def make_feature_scatters(C, D, K, model, device, dtype=torch.float32, seed=1234
     return S.to(dtype).contiguous(), scale
 
 
+def closure_benchmark(C, D, K, model_name, device, steps, lib):
+    """Secondary measurement (metric M2 of SURVEY.md 8d, N=1 only): one full closure = projection
+    of the (C,D,D) scatters through the current filters (streaming HIP kernel), fused pairwise
+    loss+grad, backward to the raw filter parameter.  Reports closures/s and the HBM roofline of
+    the projection kernel (algorithmic bytes 4*C*D^2 per launch)."""
+    import ctypes
+    import sqfa_amd
+    gen = torch.Generator(device="cpu").manual_seed(1234)
+    R = min(D, 128)
+    cov = torch.empty(C, D, D, device=device)
+    mu = torch.empty(C, D, device=device)
+    for c0 in range(0, C, 50):
+        n = min(50, C - c0)
+        A = (torch.randn(n, D, R, generator=gen) / R ** 0.5).to(device)
+        cov[c0:c0 + n] = A @ A.transpose(1, 2) + 0.05 * torch.eye(D, device=device)
+        mu[c0:c0 + n] = 0.1 * torch.randn(n, D, generator=gen).to(device)
+    torch.manual_seed(7)
+    if model_name == "sqfa":
+        model = sqfa_amd.model.SQFA(n_dim=D, n_filters=K, feature_noise=0.01).to(device)
+        prepared = model._prepare_statistics({"means": mu, "covariances": cov})
+    else:
+        model = sqfa_amd.model.SecondMomentsSQFA(n_dim=D, n_filters=K, feature_noise=0.01).to(device)
+        cov += mu[:, :, None] * mu[:, None, :]
+        prepared = model._prepare_statistics(cov)
+
+    def closure():
+        model.zero_grad()
+        loss, flags = model._fused_closure_loss(prepared)
+        loss.backward()
+        return loss
+
+    for _ in range(3):
+        closure()
+    torch.cuda.synchronize()
+    lib.sqfa_airm_profile(1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = closure()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    lib.sqfa_airm_profile(0)
+    ms, n = ctypes.c_double(0), ctypes.c_int(0)
+    lib.sqfa_project_profile_read(ctypes.byref(ms), ctypes.byref(n))
+    ms2, n2 = ctypes.c_double(0), ctypes.c_int(0)
+    lib.sqfa_airm_profile_read(ctypes.byref(ms2), ctypes.byref(n2))
+    k_ms = ms.value / max(n.value, 1)
+    byts = 4.0 * C * D * D
+    gbs = byts / (k_ms * 1e-3) / 1e9
+    return {
+        "value": steps / elapsed,
+        "unit": "closures/s",
+        "ms_per_closure": elapsed / steps * 1e3,
+        "what": f"projection F Psi_c F^T of (C={C},D={D},D) scatters + fused pairwise loss+grad + backward to the raw filters ({model_name}, K={K})",
+        "pair_kernel_ms": ms2.value / max(n2.value, 1),
+        "loss": loss.item(),
+        "roofline": {
+            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "traffic": None, "kernel": "project_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": byts,
+        },
+    }
+
+
 def cpu_baseline(S_cpu, scale, C_full, seconds_budget=25.0):
     """Time the oracle's torch-CPU port of the reference algorithm (all ordered pairs, eigh
     whitening, batched eigvalsh, autograd) on the first C_s classes of the same workload."""
@@ -112,6 +174,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-closure", action="store_true", help="skip the secondary full-closure measurement (N=1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -177,6 +240,7 @@ def main():
         kernel_ms = kmax.item()
     assert flags.tolist() == [0, 0], f"non-finite distances: {flags.tolist()}"
 
+    S_cpu = S.detach().cpu() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         evals_per_s = args.steps / elapsed
@@ -221,8 +285,12 @@ def main():
                         f"{bytes_eval / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS * 100:.3f}% of the 8 TB/s HBM roofline",
             },
         }
+        if not args.no_closure and world == 1 and dtype == torch.float32:
+            del S, grad
+            torch.cuda.empty_cache()
+            result["closure"] = closure_benchmark(C, D, K, model, device, max(10, args.steps // 2), lib)
         if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline(S.detach().cpu(), scale, C)
+            result["cpu_baseline"] = cpu_baseline(S_cpu, scale, C)
             result["speedup_vs_cpu_baseline"] = evals_per_s / result["cpu_baseline"]["value"]
         print(json.dumps(result))
     if world > 1:

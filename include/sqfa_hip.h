@@ -103,6 +103,19 @@ int sqfa_airm_pairwise(const void *A, int nA, const void *B, int nB, int m, int 
                        void *dist_out, void *eig_out, int *nonfinite_out,
                        void *workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * T_c = Psi_c F^T for c = 0..C-1: the streaming half of the projection S_c = F Psi_c F^T of the
+ * class scatter matrices into feature space.  Replaces conjugate_matrix
+ * (src/sqfa/linalg.py:19-45) as called by transform_scatters (src/sqfa/model.py:172-188):
+ * Psi (C,D,D) is read from HBM exactly once; S_c = F T_c and, in the backward pass,
+ * dL/dF = sum_c (G_c + G_c^T) T_c^T need only T (C,D,K).  Psi_c is assumed symmetric
+ * (covariance / second-moment matrices).
+ *   F (K,D) row-major, Psi (C,D,D), T_out (C,D,K) row-major; float32, D % 4 == 0, K <= 64
+ *   (SQFA_ERR_UNSUPPORTED_M otherwise: the caller keeps its own path for those shapes).
+ */
+int sqfa_project_scatters(const void *F, int K, int D, const void *Psi, int C, int dtype, void *T_out,
+                          void *stream);
+
 /* Introspection (benchmarks / development; not needed by a reference-side binding).
  *
  * sqfa_airm_set_sweep_counter: register a device buffer of two uint64 {sum of Jacobi sweeps,
@@ -114,6 +127,7 @@ int sqfa_airm_pairwise(const void *A, int nA, const void *B, int nB, int m, int 
 int sqfa_airm_set_sweep_counter(unsigned long long *device_counter2);
 int sqfa_airm_profile(int enable);
 int sqfa_airm_profile_read(double *tile_kernel_ms_total, int *launches);
+int sqfa_project_profile_read(double *kernel_ms_total, int *launches);  /* same, for sqfa_project_scatters */
 
 #ifdef __cplusplus
 }

@@ -37,9 +37,15 @@ PROTOTYPES = {
          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
          ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p],
     ),
+    "sqfa_project_scatters": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+         ctypes.c_void_p, ctypes.c_void_p],
+    ),
     "sqfa_airm_set_sweep_counter": (ctypes.c_int, [ctypes.c_void_p]),
     "sqfa_airm_profile": (ctypes.c_int, [ctypes.c_int]),
     "sqfa_airm_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), _c_int_p]),
+    "sqfa_project_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), _c_int_p]),
 }
 
 _lib = None

@@ -161,3 +161,59 @@ def generalized_eigenvalues_raw(A, B):
                         uniform_weight=0.0, shard=(0, 1), want_loss=False, want_grad=False,
                         want_dist=False, want_eig=True)
     return torch.sort(out["eig"], dim=-1, descending=True).values
+
+
+# ------------------------------------------------------------------------------------------
+# projection of the class scatter matrices (the HBM-bound stage around the pair kernel)
+
+
+def native_projection_supported(scatters, filters):
+    """The streaming kernel handles float32 (C,D,D) scatters on the GPU with D % 4 == 0 and up
+    to 64 filters; anything else keeps the plain torch expression."""
+    return (
+        scatters.is_cuda and filters.is_cuda and scatters.dtype == torch.float32 and filters.dtype == torch.float32
+        and scatters.dim() == 3 and filters.dim() == 2 and scatters.shape[-1] % 4 == 0
+        and filters.shape[0] <= 64 and filters.shape[0] <= filters.shape[1]
+        and scatters.shape[-1] == scatters.shape[-2] == filters.shape[1] and not scatters.requires_grad
+    )
+
+
+class ProjectScatters(torch.autograd.Function):
+    """S_c = F Psi_c F^T for symmetric Psi_c, reading Psi (C,D,D) from HBM once.
+
+    forward : T = Psi F^T through sqfa_project_scatters (HIP, MFMA f32), S = F T (tiny bmm)
+    backward: dL/dF = sum_c (G_c + G_c^T) T_c^T  -- needs T (C,D,K) only, not Psi.
+    Replaces conjugate_matrix (reference src/sqfa/linalg.py:19-45) in transform_scatters
+    (src/sqfa/model.py:172-188), whose autograd reads Psi a second time in the backward."""
+
+    @staticmethod
+    def forward(ctx, filters, scatters):
+        lib = _lib.load()
+        F = filters.detach().contiguous()
+        Psi = scatters.detach().contiguous()
+        K, D = F.shape
+        C = Psi.shape[0]
+        with torch.cuda.device(Psi.device):
+            T = torch.empty((C, D, K), dtype=Psi.dtype, device=Psi.device)
+            stream = torch.cuda.current_stream(Psi.device).cuda_stream
+            status = lib.sqfa_project_scatters(_ptr(F), K, D, _ptr(Psi), C, _dtype_code(Psi), _ptr(T),
+                                               ctypes.c_void_p(stream))
+        _lib.check(status, "sqfa_project_scatters")
+        ctx.save_for_backward(T)
+        return torch.matmul(F.unsqueeze(0), T)
+
+    @staticmethod
+    def backward(ctx, gS):
+        (T,) = ctx.saved_tensors
+        sym = gS + gS.transpose(1, 2)
+        C, D, K = T.shape
+        # (K, C*K) @ (C*K, D)
+        gF = torch.matmul(sym.permute(1, 0, 2).reshape(K, C * K), T.permute(0, 2, 1).reshape(C * K, D))
+        return gF, None
+
+
+def project_scatters(scatters, filters):
+    """(C,D,D) x (K,D) -> (C,K,K); native streaming kernel when supported, torch otherwise."""
+    if native_projection_supported(scatters, filters):
+        return ProjectScatters.apply(filters, scatters)
+    return None

@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <utility>
 #include <vector>
 
 #include "../../include/sqfa_hip.h"
@@ -46,6 +47,14 @@ static unsigned long long* g_sweep_counter = nullptr;
 struct EventPair { hipEvent_t a, b; };
 static bool g_profile = false;
 static std::vector<EventPair> g_events;
+}  // namespace sqfa
+// shared with project_kernel.hip
+bool sqfa_profile_enabled() { return sqfa::g_profile; }
+std::vector<std::pair<hipEvent_t, hipEvent_t>>& sqfa_project_events() {
+  static std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  return ev;
+}
+namespace sqfa {
 
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -277,6 +286,24 @@ int sqfa_airm_profile_read(double* tile_kernel_ms_total, int* launches) {
   }
   g_events.clear();
   if (tile_kernel_ms_total) *tile_kernel_ms_total = total;
+  if (launches) *launches = n;
+  return SQFA_OK;
+}
+
+int sqfa_project_profile_read(double* kernel_ms_total, int* launches) {
+  double total = 0.0;
+  int n = 0;
+  for (auto& ev : sqfa_project_events()) {
+    float ms = 0.f;
+    if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+      total += ms;
+      ++n;
+    }
+    hipEventDestroy(ev.first);
+    hipEventDestroy(ev.second);
+  }
+  sqfa_project_events().clear();
+  if (kernel_ms_total) *kernel_ms_total = total;
   if (launches) *launches = n;
   return SQFA_OK;
 }

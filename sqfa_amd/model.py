@@ -83,8 +83,15 @@ class SecondMomentsSQFA(nn.Module):
 
     # ------------------------------------------------------------------ transforms
     def transform_scatters(self, data_scatters):
-        """(C,D,D) scatter matrices -> (C,K,K) feature scatters F S F^T (reference: model.py:172-188)."""
-        return conjugate_matrix(data_scatters, self.filters)
+        """(C,D,D) scatter matrices -> (C,K,K) feature scatters F S F^T (reference: model.py:172-188).
+        float32 GPU inputs go through the single-pass streaming kernel (scatters are read from
+        HBM once per closure, forward and backward together); other inputs use the torch
+        expression of conjugate_matrix."""
+        filters = self.filters
+        native = _native.project_scatters(data_scatters, filters)
+        if native is not None:
+            return native.squeeze(0) if native.shape[0] == 1 else native
+        return conjugate_matrix(data_scatters, filters)
 
     def transform(self, data_points):
         """(N,D) points -> (N,K) features (reference: model.py:222-237)."""

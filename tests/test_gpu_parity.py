@@ -228,3 +228,30 @@ def test_exactly_degenerate_pairs(m, dtype):
     expect = m * torch.log(torch.tensor([[1, .5, 1, 2], [2, 1, 2, 4], [1, .5, 1, 2], [.5, .25, .5, 1.]],
                                         dtype=dtype, device=DEV)) ** 2
     assert torch.allclose(Dt, expect, atol=1e-5)
+
+
+@pytest.mark.parametrize("C,D,K", [(3, 8, 2), (5, 64, 16), (7, 100, 5), (4, 784, 16), (2, 2048, 32), (3, 132, 33),
+                                   (2, 256, 64), (1, 16, 16), (6, 60, 48)])
+def test_streaming_projection_vs_torch(C, D, K):
+    """sqfa_project_scatters + ProjectScatters against the float64 torch expression of
+    conjugate_matrix (values and the gradient with respect to the filters)."""
+    from sqfa_amd import _native, linalg
+    g = torch.Generator().manual_seed(C * 1000 + D + K)
+    A = torch.randn(C, D, D // 2 + 1, generator=g, dtype=torch.float64)
+    Psi = (A @ A.transpose(1, 2) / A.shape[-1] + 0.05 * torch.eye(D, dtype=torch.float64))
+    F = torch.randn(K, D, generator=g, dtype=torch.float64)
+    W = torch.randn(C, K, K, generator=g, dtype=torch.float64)
+    F64 = F.clone().requires_grad_(True)
+    S64 = linalg.conjugate_matrix(Psi, F64)
+    (W.reshape(S64.shape) * S64).sum().backward()
+    Fg = F.float().to(DEV).requires_grad_(True)
+    Pg = Psi.float().to(DEV)
+    assert _native.native_projection_supported(Pg, Fg)
+    S = _native.project_scatters(Pg, Fg)
+    assert S.shape == (C, K, K)
+    (W.float().to(DEV) * S).sum().backward()
+    assert rel_err(S.detach().cpu(), S64.detach().reshape(C, K, K)) < 2e-6
+    assert rel_err(Fg.grad.cpu(), F64.grad) < 2e-6
+    # unsupported shapes fall back (D not a multiple of 4, float64)
+    assert _native.project_scatters(Pg[:, :D - 1, :D - 1].contiguous(), Fg[:, :D - 1].detach().contiguous()) is None
+    assert _native.project_scatters(Psi.to(DEV), F.to(DEV)) is None
