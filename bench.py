@@ -136,6 +136,17 @@ def closure_benchmark(C, D, K, model_name, device, steps, lib):
     }
 
 
+def pmc_traffic(kernel, workload, dtype):
+    """HBM bytes per launch from the committed rocprofv3 --pmc summary (collected in separate
+    FETCH_SIZE / WRITE_SIZE passes as MI355X_MICROARCH.md prescribes; see the file's `correction`).
+    Only quoted for the workload it was measured on."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_c3.json")
+    if workload != "c3" or dtype != "f32" or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        return json.load(fh)["kernels"].get(kernel, {}).get("hbm_bytes_per_launch")
+
+
 def cpu_baseline(S_cpu, scale, C_full, seconds_budget=25.0):
     """Time the oracle's torch-CPU port of the reference algorithm (all ordered pairs, eigh
     whitening, batched eigvalsh, autograd) on the first C_s classes of the same workload."""
@@ -275,7 +286,8 @@ def main():
                 "peak": FP32_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved_tf / FP32_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": pmc_traffic("pair_tile_kernel", args.workload, args.dtype) if world == 1 else None,
+                "traffic_unit": "bytes per launch (profiles/r1_pmc_c3.json)",
                 "kernel": "pair_tile_kernel",
                 "kernel_ms": kernel_ms,
                 "algorithmic_flops_per_launch": flops_launch,
@@ -289,6 +301,8 @@ def main():
             del S, grad
             torch.cuda.empty_cache()
             result["closure"] = closure_benchmark(C, D, K, model, device, max(10, args.steps // 2), lib)
+            result["closure"]["roofline"]["traffic"] = pmc_traffic("project_kernel", args.workload, args.dtype)
+            result["closure"]["roofline"]["traffic_unit"] = "bytes per launch (profiles/r1_pmc_c3.json)"
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(S_cpu, scale, C)
             result["speedup_vs_cpu_baseline"] = evals_per_s / result["cpu_baseline"]["value"]
