@@ -19,6 +19,19 @@ def __dir__():
     return __all__
 
 
+# LBFGS' two-loop recursion is ~200 tiny vector operations per iteration (history_size=100).
+# On a GPU every one of them is a kernel launch (~5-10 us), which for the small parameter of
+# SQFA (K x D <= 16 x 3072 floats) is far more than the closure itself at small C (6.6 ms per
+# closure at C=10 against 0.8 ms of closure work).  With this switch on, torch.optim.LBFGS
+# runs -- unmodified -- on HOST copies of the parameters; each closure call pushes the current
+# host values into the device parameters, evaluates loss and gradient on the GPU, and pulls the
+# gradient back (two small copies).  Same arithmetic, same stopping rule.  Only used while the
+# parameter vector stays below torch's intra-op parallel grain (32768 elements): beyond it
+# the host vector ops fan out over every hardware thread the process can see, which is far
+# slower than the GPU launches on an oversubscribed host.
+HOST_SIDE_LBFGS = True
+HOST_SIDE_LBFGS_MAX_NUMEL = 32768
+
 _NAN_MSG = "Some distances between classes are NaN. Try using float64 or a different regularization parameter."
 _INF_MSG = "Some distances between classes are inf. Try using float64 or a different regularization parameter."
 
@@ -52,24 +65,49 @@ def fitting_loop(model, data_statistics, max_epochs=200, lr=0.1, atol=1e-6, show
     """Learn the filters with LBFGS.  Same arguments, stopping rule (|dloss| < atol for three
     consecutive epochs), messages and return value as the reference's fitting_loop
     (src/sqfa/_optim.py:33-145); extra keyword arguments go to torch.optim.LBFGS."""
-    optimizer = torch.optim.LBFGS(model.parameters(), lr=lr, **kwargs)
-    n_classes = _n_classes(data_statistics)
+    device_params = list(model.parameters())
+    use_host = (HOST_SIDE_LBFGS and len(device_params) > 0 and all(p.is_cuda for p in device_params)
+                and sum(p.numel() for p in device_params) <= HOST_SIDE_LBFGS_MAX_NUMEL)
+    if use_host:
+        opt_params = [torch.nn.Parameter(p.detach().cpu().clone()) for p in device_params]
+    else:
+        opt_params = device_params
+    optimizer = torch.optim.LBFGS(opt_params, lr=lr, **kwargs)
+
+    def push_parameters():
+        if use_host:
+            with torch.no_grad():
+                for p, h in zip(device_params, opt_params):
+                    p.copy_(h, non_blocking=True)
+    prepared = model._prepare_statistics(data_statistics)
+    n_classes = model._n_classes_total(prepared) if hasattr(model, "_n_classes_total") else _n_classes(data_statistics)
     if n_classes < 2:
         raise ValueError("At least two classes are needed to fit the filters.")  # SURVEY.md Q8
-    prepared = model._prepare_statistics(data_statistics)
     rows, cols = torch.tril_indices(n_classes, n_classes, offset=-1)
 
     def closure():
         optimizer.zero_grad()
+        push_parameters()
+        if use_host:
+            for p in device_params:
+                p.grad = None
         fused = model._fused_closure_loss(prepared)
         if fused is not None:
             loss, flags = fused
             raise_on_flags(flags)
         else:
+            if getattr(model, "class_shard", None) is not None:
+                raise NotImplementedError("class-sharded statistics need one of the native distance operators")
             distances = model.get_class_distances(prepared, regularized=True)
             check_distances_valid(distances)
             loss = -distances[rows.to(distances.device), cols.to(distances.device)].mean()
         loss.backward()
+        if hasattr(model, "_sync_gradients"):
+            model._sync_gradients()
+        if use_host:
+            for p, h in zip(device_params, opt_params):
+                h.grad = p.grad.detach().cpu()
+            return loss.detach().cpu()
         return loss
 
     losses, times = [], []
@@ -93,6 +131,7 @@ def fitting_loop(model, data_statistics, max_epochs=200, lr=0.1, atol=1e-6, show
             f"Reached max_epochs ({max_epochs}) without meeting stopping criteria."
             + "Consider increasing max_epochs, changing initialization or using dtype=torch.float64."
         )
+    push_parameters()  # the values LBFGS ended on
     if return_loss:
         return torch.tensor(losses), torch.tensor(times)
     return None

@@ -75,7 +75,8 @@ class SecondMomentsSQFA(nn.Module):
         self.distance_fun = distances.affine_invariant if distance_fun is None else distance_fun
         self.constraint = constraint
         self._add_constraint(constraint)
-        self.pair_shard = None  # optional sqfa_amd.parallel.PairShard for multi-GPU fits
+        self.pair_shard = None   # optional sqfa_amd.parallel.PairShard for multi-GPU fits
+        self.class_shard = None  # optional sqfa_amd.parallel.ClassShard: statistics hold local classes only
 
     @staticmethod
     def _noise_matrix(feature_noise, k):
@@ -128,12 +129,24 @@ class SecondMomentsSQFA(nn.Module):
             return None
         _, scale, sqrt_mode = spec
         S = self._fused_input(prepared)
+        if self.class_shard is not None:
+            S = self.class_shard.gather(S)
         C = S.shape[0]
         weight = -1.0 / (C * (C - 1) // 2)
         shard, reducer = (0, 1), None
         if self.pair_shard is not None:
             shard, reducer = self.pair_shard.shard, self.pair_shard.reduce
         return _native.PairwiseLoss.apply(S, scale, distances.EPSILON, sqrt_mode, weight, shard, reducer)
+
+    def _sync_gradients(self):
+        """Called by the fitting loop after backward: sums the filter gradient over class shards."""
+        if self.class_shard is not None:
+            self.class_shard.reduce_gradients(self.parameters())
+
+    def _n_classes_total(self, prepared):
+        if self.class_shard is not None:
+            return self.class_shard.n_classes
+        return prepared["means"].shape[0] if isinstance(prepared, dict) else prepared.shape[0]
 
     # ------------------------------------------------------------------ fitting
     def fit_pca(self, X=None, data_statistics=None):
@@ -144,6 +157,13 @@ class SecondMomentsSQFA(nn.Module):
         k = self.filters.shape[0]
         if data_statistics is None:
             components = pca(X, k)
+        elif self.class_shard is not None:
+            # statistics hold the local classes only: average the scatters over all ranks first
+            local_sum = _stats_to_scatter(data_statistics).sum(dim=0)
+            torch.distributed.all_reduce(local_sum, group=self.class_shard.group)
+            if k > local_sum.shape[-1]:
+                raise ValueError("n_components must be less than or equal to n_dim.")
+            components = pca(local_sum / self.class_shard.n_classes, n_components=k)
         else:
             components = pca_from_scatter(_stats_to_scatter(data_statistics), k)
         self._replace_filters(components)

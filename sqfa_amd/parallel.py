@@ -10,7 +10,7 @@ performs the identical LBFGS update.
 import torch
 import torch.distributed as dist
 
-__all__ = ["PairShard"]
+__all__ = ["PairShard", "ClassShard"]
 
 
 class PairShard:
@@ -40,3 +40,53 @@ class PairShard:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
         flags_out = buf[1:3].round().to(torch.int32)
         return buf[0].clone(), flags_out, buf[3:].reshape(grad.shape).clone()
+
+
+class _GatherClasses(torch.autograd.Function):
+    """all_gather of the per-rank slices of the feature scatters along the class axis.  In the
+    backward pass every rank already holds the FULL dL/dS (PairShard.reduce summed it), so the
+    gradient of the local slice is just the matching rows: no second collective."""
+
+    @staticmethod
+    def forward(ctx, S_local, shard):
+        ctx.shard = shard
+        parts = [S_local.new_empty((n,) + tuple(S_local.shape[1:])) for n in shard.counts]
+        dist.all_gather(parts, S_local.contiguous(), group=shard.group)
+        return torch.cat(parts, dim=0)
+
+    @staticmethod
+    def backward(ctx, g_full):
+        sh = ctx.shard
+        return g_full[sh.offset:sh.offset + sh.counts[sh.rank]], None
+
+
+class ClassShard:
+    """Class-sharding of the PROJECTION for large D: rank r holds the
+    (C_r, D, D) statistics of its own classes only, projects them (C_r, m, m), and the small
+    feature scatters are all-gathered so that every rank can evaluate its tile shard of ALL
+    pairs.  After the backward pass the partial filter gradients (sums over local classes)
+    are all-reduced.  Use together with PairShard:
+
+    >>> model.pair_shard = PairShard(); model.class_shard = ClassShard(n_local_classes)
+    >>> model.fit(data_statistics=local_statistics)
+    """
+
+    def __init__(self, n_local, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world_size = dist.get_world_size(group)
+        counts = [None] * self.world_size
+        dist.all_gather_object(counts, int(n_local), group=group)
+        self.counts = counts
+        self.offset = sum(counts[: self.rank])
+        self.n_classes = sum(counts)
+
+    def gather(self, S_local):
+        if S_local.shape[0] != self.counts[self.rank]:
+            raise ValueError("local statistics do not match the class count announced to ClassShard")
+        return _GatherClasses.apply(S_local, self)
+
+    def reduce_gradients(self, parameters):
+        for prm in parameters:
+            if prm.grad is not None:
+                dist.all_reduce(prm.grad, op=dist.ReduceOp.SUM, group=self.group)

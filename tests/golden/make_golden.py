@@ -323,6 +323,45 @@ def g5():
     np.savez_compressed(os.path.join(HERE, "g5_quirks.npz"), **out)
 
 
+# ---------------------------------------------------------------- G6
+def c2_statistics(C=100, D=784, seed=1234, dtype=torch.float64):
+    """BASELINE config c2-shaped synthetic Gaussians (SURVEY 8d generator), regenerated from the
+    seed by the tests (the (C,D,D) tensor is too large to store): torch CPU generator only."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    R = min(D, 128)
+    cov = torch.empty(C, D, D, dtype=dtype)
+    mu = torch.empty(C, D, dtype=dtype)
+    for c0 in range(0, C, 50):
+        n = min(50, C - c0)
+        A = (torch.randn(n, D, R, generator=g, dtype=torch.float32) / R ** 0.5).to(dtype)
+        cov[c0:c0 + n] = A @ A.transpose(1, 2) + 0.05 * torch.eye(D, dtype=dtype)
+        mu[c0:c0 + n] = (0.1 * torch.randn(n, D, generator=g, dtype=torch.float32)).to(dtype)
+    return {"means": mu, "covariances": cov}
+
+
+def g6():
+    """Full float64 fits of the reference on the c2-shaped configuration (C=100, n_dim=784,
+    n_filters=8, feature_noise=0.01, fit_pca init): per-epoch losses and learned filters."""
+    out = {}
+    torch.set_default_dtype(torch.float64)
+    stats = c2_statistics()
+    out["check_cov00"] = stats["covariances"][0, :4, :4].numpy()
+    for model_name in ("smsqfa", "sqfa"):
+        cls = sqfa.model.SQFA if model_name == "sqfa" else sqfa.model.SecondMomentsSQFA
+        model = cls(n_dim=784, n_filters=8, feature_noise=0.01).double()
+        model.fit_pca(data_statistics=stats)
+        out[f"{model_name}_init"] = model.filters.detach().numpy().copy()
+        import time as _t
+        t0 = _t.time()
+        loss, _t_ = model.fit(data_statistics=stats, max_epochs=300, show_progress=False, return_loss=True)
+        out[f"{model_name}_seconds"] = np.array(_t.time() - t0)
+        out[f"{model_name}_loss"] = loss.numpy()
+        out[f"{model_name}_filters"] = model.filters.detach().numpy()
+        print(model_name, "epochs", len(loss), "seconds", float(out[f"{model_name}_seconds"]), flush=True)
+    torch.set_default_dtype(torch.float32)
+    np.savez_compressed(os.path.join(HERE, "g6_fit_c2.npz"), **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g1x", "g2", "g3", "g4", "g5"]
     for name in which:

@@ -102,3 +102,17 @@ def check_fit(dname, model_name, K, noise, epochs, device, tol_loss, tol_filters
     assert elapsed.shape == loss.shape
     assert np.abs(loss.numpy() - ref_loss).max() <= tol_loss
     assert rel_err(model.filters.detach().cpu(), G4[f"{key}_filters"]) <= tol_filters
+
+
+def c2_statistics(C=100, D=784, seed=1234, dtype=torch.float64):
+    """Same generator as tests/golden/make_golden.py:c2_statistics (BASELINE config c2 shape)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    R = min(D, 128)
+    cov = torch.empty(C, D, D, dtype=dtype)
+    mu = torch.empty(C, D, dtype=dtype)
+    for c0 in range(0, C, 50):
+        n = min(50, C - c0)
+        A = (torch.randn(n, D, R, generator=g, dtype=torch.float32) / R ** 0.5).to(dtype)
+        cov[c0:c0 + n] = A @ A.transpose(1, 2) + 0.05 * torch.eye(D, dtype=dtype)
+        mu[c0:c0 + n] = (0.1 * torch.randn(n, D, generator=g, dtype=torch.float32)).to(dtype)
+    return {"means": mu, "covariances": cov}

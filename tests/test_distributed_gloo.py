@@ -41,7 +41,17 @@ def _worker(rank, world, port, q):
         model.fit_pca(data_statistics=stats)
         model.pair_shard = shard
         fl, _ = model.fit(data_statistics=stats, max_epochs=3, show_progress=False, return_loss=True)
-        q.put((rank, loss.item(), Sg.grad.numpy(), flags.tolist(), fl.numpy(), model.filters.detach().numpy()))
+        # class-sharded projection: each rank holds 10 of the 20 classes
+        from sqfa_amd.parallel import ClassShard
+        lo, hi = (0, 10) if rank == 0 else (10, 20)
+        local = {k: v[lo:hi].clone() for k, v in stats.items()}
+        model2 = mc.make_model("sqfa", 50, 2, 1e-3, "sphere", torch.float64, "cpu")
+        model2.pair_shard = shard
+        model2.class_shard = ClassShard(hi - lo)
+        model2.fit_pca(data_statistics=local)
+        fl2, _ = model2.fit(data_statistics=local, max_epochs=3, show_progress=False, return_loss=True)
+        q.put((rank, loss.item(), Sg.grad.numpy(), flags.tolist(), fl.numpy(), model.filters.detach().numpy(),
+               fl2.numpy(), model2.filters.detach().numpy()))
     finally:
         dist.destroy_process_group()
 
@@ -60,7 +70,11 @@ def test_two_rank_pair_shard_matches_single_process():
         assert p.exitcode == 0
     G1 = load_golden("g1_airm_self.npz")
     G4 = load_golden("g4_fit.npz")
-    (_, l0, g0, f0, fl0, F0), (_, l1, g1, f1, fl1, F1) = results
+    (_, l0, g0, f0, fl0, F0, fc0, Fc0), (_, l1, g1, f1, fl1, F1, fc1, Fc1) = results
+    # class-sharded fit: identical on both ranks, same trajectory as the single-process reference fit
+    assert np.array_equal(Fc0, Fc1)
+    assert np.abs(fc0 - G4["syn_sqfa_K2_e3_loss"]).max() < 1e-6
+    assert np.linalg.norm(Fc0 - G4["syn_sqfa_K2_e3_filters"]) < 1e-7 * np.linalg.norm(Fc0)
     assert l0 == l1 and np.array_equal(g0, g1) and np.array_equal(F0, F1)      # identical on both ranks
     assert f0 == [0, 0] and f1 == [0, 0]
     assert abs(l0 - float(G1["C37_m16_loss_f64"])) < 1e-12

@@ -101,3 +101,26 @@ def test_fit_from_points_on_gpu_and_error_paths():
     S[1] = -S[1]
     with pytest.raises(ValueError, match="NaN"):
         bad.fit(data_statistics=S, max_epochs=2, show_progress=False)
+
+
+@pytest.mark.parametrize("model_name", ["smsqfa", "sqfa"])
+def test_c2_config_full_fit_matches_reference_f64(model_name):
+    """BASELINE config c2 shape (C=100, n_dim=784, n_filters=8, feature_noise=0.01): a full
+    float64 fit on the GPU against the reference's own float64 CPU fit (golden G6): same
+    number of epochs, per-epoch losses, and learned filters to 1e-5 (north_star criterion)."""
+    from conftest import load_golden
+    G6 = load_golden("g6_fit_c2.npz")
+    stats = mc.c2_statistics()
+    assert np.allclose(stats["covariances"][0, :4, :4].numpy(), G6["check_cov00"], rtol=1e-12)
+    stats = {k: v.to(DEV) for k, v in stats.items()}
+    model = mc.make_model(model_name, 784, 8, 0.01, "sphere", torch.float64, DEV)
+    model.fit_pca(data_statistics=stats)
+    assert rel_err(model.filters.detach().cpu(), G6[f"{model_name}_init"]) < 1e-9
+    loss, t = model.fit(data_statistics=stats, max_epochs=300, show_progress=False, return_loss=True)
+    ref = G6[f"{model_name}_loss"]
+    assert len(loss) == len(ref)
+    assert np.abs(loss.numpy() - ref).max() < 1e-6
+    err = rel_err(model.filters.detach().cpu(), G6[f"{model_name}_filters"])
+    print(f"c2 {model_name}: {len(loss)} epochs, GPU fit {t[-1].item():.2f} s vs reference CPU "
+          f"{float(G6[f'{model_name}_seconds']):.1f} s (8 vCPU build container), filters rel err {err:.2e}")
+    assert err < 1e-5
