@@ -85,11 +85,22 @@ static WorkspaceLayout layout(int nA, int nBeff, const Geometry& g, size_t esz, 
 //   per pivot column (one LDS round trip per entry and pivot instead of a serial row loop).
 //   Inverse: X = L^-1 row by row; row r needs rows < r, columns are independent; the inner
 //   sum runs over k in parallel chunks of 4 lanes per column.
-template <typename T>
+// 1/sqrt(x) in double without the IEEE sqrt/divide sequences: hardware estimate + 2 Newton steps
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+}
+
+template <typename T, int MAXM>
 __global__ __launch_bounds__(256) void cholesky_kernel(const T* __restrict__ S, int m, int MR,
                                                        T* __restrict__ LT, T* __restrict__ Linv) {
-  __shared__ double a[64][65];
-  __shared__ double b[64][65];
+  // LDS sized for the padded size class (MAXM >= m) so that small problems keep many
+  // workgroups per CU resident
+  __shared__ double a[MAXM][MAXM + 1];
+  __shared__ double b[MAXM][MAXM + 1];
+  __shared__ double rd[MAXM];  // 1 / L[k][k]
   const int c = blockIdx.x, t = threadIdx.x;
   const T* s = S + (size_t)c * m * m;
   for (int idx = t; idx < m * m; idx += 256) {
@@ -98,9 +109,13 @@ __global__ __launch_bounds__(256) void cholesky_kernel(const T* __restrict__ S, 
   }
   __syncthreads();
   for (int k = 0; k < m; ++k) {
-    const double sd = sqrt(a[k][k]);
+    // a non-positive or NaN pivot gives NaN here and everywhere downstream
+    const double rs = fast_rsqrt(a[k][k]);
     __syncthreads();
-    for (int r = k + t; r < m; r += 256) a[r][k] = (r == k) ? sd : a[r][k] / sd;
+    for (int r = k + t; r < m; r += 256) {
+      a[r][k] *= rs;  // r == k: akk * rs = sqrt(akk)
+      if (r == k) rd[k] = rs;
+    }
     __syncthreads();
     // trailing update of the lower triangle: entries (r, c2) with k < c2 <= r < m
     const int n = m - k - 1;
@@ -108,9 +123,10 @@ __global__ __launch_bounds__(256) void cholesky_kernel(const T* __restrict__ S, 
       const int r = k + 1 + e / n, c2 = k + 1 + e % n;
       if (c2 <= r) a[r][c2] -= a[r][k] * a[c2][k];
     }
-    __syncthreads();
   }
-  // inverse: thread group of 4 lanes per column col (64 columns x 4 = 256 threads)
+  __syncthreads();
+  // inverse X = L^-1, row by row; 4 lanes per column (always inside one wave, so rows only
+  // need the wave's own program order, no workgroup barrier)
   {
     const int col = t >> 2, part = t & 3;
     for (int r = 0; r < m; ++r) {
@@ -120,10 +136,12 @@ __global__ __launch_bounds__(256) void cholesky_kernel(const T* __restrict__ S, 
       }
       acc += __shfl_xor(acc, 1, 64);
       acc += __shfl_xor(acc, 2, 64);
-      if (part == 0 && col <= r && col < m) b[r][col] = ((col == r ? 1.0 : 0.0) - acc) / a[r][r];
-      __syncthreads();
+      if (part == 0 && col <= r && col < m) b[r][col] = ((col == r ? 1.0 : 0.0) - acc) * rd[r];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   }
+  __syncthreads();
   const size_t base = (size_t)c * MR * MR;
   for (int idx = t; idx < MR * MR; idx += 256) {
     const int r = idx / MR, k = idx % MR;
@@ -379,23 +397,30 @@ int sqfa_airm_pairwise(const void* A, int nA, const void* B, int nB, int m, int 
   p.uniform_weight = uniform_weight;
 
   // K0: factors
+  auto launch_chol = [&](auto zero, const void* src, int n, void* lt, void* li) {
+    using T = decltype(zero);
+    const T* sp = static_cast<const T*>(src);
+    T* ltp = static_cast<T*>(lt);
+    T* lip = static_cast<T*>(li);
+    if (m <= 16) hipLaunchKernelGGL((cholesky_kernel<T, 16>), dim3(n), dim3(256), 0, stream, sp, m, g.MR, ltp, lip);
+    else if (m <= 32) hipLaunchKernelGGL((cholesky_kernel<T, 32>), dim3(n), dim3(256), 0, stream, sp, m, g.MR, ltp, lip);
+    else hipLaunchKernelGGL((cholesky_kernel<T, 64>), dim3(n), dim3(256), 0, stream, sp, m, g.MR, ltp, lip);
+  };
+  void* ws_lt = ws + w.off_lt;
+  void* ws_li = ws + w.off_linv;
   if (dtype == SQFA_F32) {
-    float* LT = reinterpret_cast<float*>(ws + w.off_lt);
-    float* LI = reinterpret_cast<float*>(ws + w.off_linv);
     if (self_mode) {
-      hipLaunchKernelGGL(cholesky_kernel<float>, dim3(nA), dim3(256), 0, stream, static_cast<const float*>(A), m, g.MR, LT, LI);
+      launch_chol(0.0f, A, nA, ws_lt, ws_li);
     } else {
-      hipLaunchKernelGGL(cholesky_kernel<float>, dim3(nA), dim3(256), 0, stream, static_cast<const float*>(A), m, g.MR, LT, (float*)nullptr);
-      hipLaunchKernelGGL(cholesky_kernel<float>, dim3(nB), dim3(256), 0, stream, static_cast<const float*>(B), m, g.MR, (float*)nullptr, LI);
+      launch_chol(0.0f, A, nA, ws_lt, nullptr);
+      launch_chol(0.0f, B, nB, nullptr, ws_li);
     }
   } else {
-    double* LT = reinterpret_cast<double*>(ws + w.off_lt);
-    double* LI = reinterpret_cast<double*>(ws + w.off_linv);
     if (self_mode) {
-      hipLaunchKernelGGL(cholesky_kernel<double>, dim3(nA), dim3(256), 0, stream, static_cast<const double*>(A), m, g.MR, LT, LI);
+      launch_chol(0.0, A, nA, ws_lt, ws_li);
     } else {
-      hipLaunchKernelGGL(cholesky_kernel<double>, dim3(nA), dim3(256), 0, stream, static_cast<const double*>(A), m, g.MR, LT, (double*)nullptr);
-      hipLaunchKernelGGL(cholesky_kernel<double>, dim3(nB), dim3(256), 0, stream, static_cast<const double*>(B), m, g.MR, (double*)nullptr, LI);
+      launch_chol(0.0, A, nA, ws_lt, nullptr);
+      launch_chol(0.0, B, nB, nullptr, ws_li);
     }
   }
   hipError_t e = hipGetLastError();

@@ -36,15 +36,26 @@ def oas_covariance(points, assume_centered=False):
 
 def class_statistics(points, labels, estimator="empirical"):
     """Per-class mean, covariance and second moment.  Labels are integers 0..C-1
-    (reference: statistics.py:8-54; keys 'means', 'covariances', 'second_moments')."""
+    (reference: statistics.py:8-54; keys 'means', 'covariances', 'second_moments').
+
+    The reference selects each class with a boolean mask inside a Python loop (one
+    ``nonzero`` host sync per class).  Here the points are sorted by label once (stable, so
+    every class keeps its original point order and the sums are the same), the class
+    boundaries come back in ONE host transfer, and each class is a contiguous slice."""
     if estimator not in ("empirical", "oas"):
         raise ValueError("estimator must be 'empirical' or 'oas'")
+    labels = labels.to(points.device)
     n_classes = int(labels.max()) + 1
     d = points.shape[-1]
+    order = torch.sort(labels, stable=True).indices
+    bounds = torch.cumsum(torch.bincount(labels, minlength=n_classes), 0).tolist()
+    sorted_points = points[order]
     means = points.new_zeros(n_classes, d)
     covs = points.new_zeros(n_classes, d, d)
+    start = 0
     for c in range(n_classes):
-        pts = points[labels == c]
+        pts = sorted_points[start:bounds[c]]
+        start = bounds[c]
         means[c] = pts.mean(dim=0)
         covs[c] = sample_covariance(pts) if estimator == "empirical" else oas_covariance(pts)
     second = covs + means[:, :, None] * means[:, None, :]
