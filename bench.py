@@ -194,6 +194,10 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    # rehearsal aid: SQFA_BENCH_REHEARSAL=1 runs all ranks on cuda:0 over gloo (one-GPU box)
+    rehearsal = os.environ.get("SQFA_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -203,7 +207,10 @@ def main():
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
         shard = PairShard()
     else:
         shard = PairShard(rank=0, world_size=1)
@@ -217,10 +224,18 @@ def main():
     lib = _lib.load()
 
     def step():
+        # exactly what sqfa_amd._native.PairwiseLoss.forward does inside a closure
+        if world > 1:
+            fused = torch.empty(S.numel() + 3, dtype=S.dtype, device=device)
+            out = _native.hip_pair_backend(S, None, scale=scale, eps=_native.EPSILON, sqrt_mode=True, weights=None,
+                                           uniform_weight=weight, shard=shard.shard, want_loss=True, want_grad=True,
+                                           want_dist=False, want_eig=False, out_loss=fused[0],
+                                           out_gradA=fused[3:].view(S.shape))
+            return shard.reduce_fused(fused, out["nonfinite"], S.shape)
         out = _native.hip_pair_backend(S, None, scale=scale, eps=_native.EPSILON, sqrt_mode=True, weights=None,
                                        uniform_weight=weight, shard=shard.shard, want_loss=True, want_grad=True,
                                        want_dist=False, want_eig=False)
-        return shard.reduce(out["loss"], out["nonfinite"], out["gradA"])
+        return out["loss"], out["nonfinite"], out["gradA"]
 
     def fence():
         if world > 1:

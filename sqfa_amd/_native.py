@@ -31,7 +31,7 @@ def max_dim():
 
 
 def hip_pair_backend(A, B, *, scale, eps, sqrt_mode, weights, uniform_weight, shard,
-                     want_loss, want_grad, want_dist, want_eig):
+                     want_loss, want_grad, want_dist, want_eig, out_loss=None, out_gradA=None):
     """Run sqfa_airm_pairwise on the current stream.  A (nA,m,m); B (nB,m,m) or None (self).
     Returns dict(loss, gradA, gradB, dist, eig, nonfinite) of freshly allocated tensors
     (None where not requested)."""
@@ -62,9 +62,10 @@ def hip_pair_backend(A, B, *, scale, eps, sqrt_mode, weights, uniform_weight, sh
     nBe = nA if B is None else nB
     with torch.cuda.device(dev):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        loss = torch.zeros((), dtype=A.dtype, device=dev) if want_loss else None
+        # out_loss / out_gradA: caller-provided views (e.g. into a fused all-reduce buffer)
+        loss = (out_loss if out_loss is not None else torch.zeros((), dtype=A.dtype, device=dev)) if want_loss else None
         nonfinite = torch.zeros(2, dtype=torch.int32, device=dev)
-        gradA = torch.empty_like(A) if want_grad else None
+        gradA = (out_gradA if out_gradA is not None else torch.empty_like(A)) if want_grad else None
         gradB = torch.empty_like(B) if (want_grad and B is not None) else None
         if want_dist:
             dist = (torch.zeros if shard[1] > 1 else torch.empty)((nA, nBe), dtype=A.dtype, device=dev)
@@ -139,11 +140,20 @@ class PairwiseLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, S, scale, eps, sqrt_mode, weight, shard, reducer):
+        extra = {}
+        fused = None
+        if reducer is not None and shard[1] > 1 and _pair_backend is hip_pair_backend:
+            # the kernel writes loss and gradient straight into the all-reduce buffer
+            # [loss, nan, inf, grad...]: no packing copies
+            fused = torch.empty(S.numel() + 3, dtype=S.dtype, device=S.device)
+            extra = {"out_loss": fused[0], "out_gradA": fused[3:].view(S.shape)}
         out = _pair_backend(S, None, scale=scale, eps=eps, sqrt_mode=sqrt_mode, weights=None,
                             uniform_weight=weight, shard=shard, want_loss=True, want_grad=True,
-                            want_dist=False, want_eig=False)
+                            want_dist=False, want_eig=False, **extra)
         loss, nonfinite, grad = out["loss"], out["nonfinite"], out["gradA"]
-        if reducer is not None:
+        if fused is not None:
+            loss, nonfinite, grad = reducer.__self__.reduce_fused(fused, nonfinite, S.shape)
+        elif reducer is not None:
             loss, nonfinite, grad = reducer(loss, nonfinite, grad)
         ctx.save_for_backward(grad)
         ctx.mark_non_differentiable(nonfinite)

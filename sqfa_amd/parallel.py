@@ -28,6 +28,12 @@ class PairShard:
     def shard(self):
         return (self.rank, self.world_size)
 
+    def reduce_fused(self, buf, flags, shape):
+        """Same as `reduce` for a buffer [loss, -, -, grad...] the kernel has already filled."""
+        buf[1:3] = flags.to(buf.dtype)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        return buf[0], buf[1:3].round().to(torch.int32), buf[3:].view(shape)
+
     def reduce(self, loss, flags, grad):
         """Sum (loss, flags, grad) over the ranks with a single all-reduce."""
         if self.world_size == 1:
