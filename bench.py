@@ -151,7 +151,15 @@ def cpu_baseline(S_cpu, scale, C_full, seconds_budget=25.0):
     """Time the oracle's torch-CPU port of the reference algorithm (all ordered pairs, eigh
     whitening, batched eigvalsh, autograd) on the first C_s classes of the same workload."""
     from oracle import reference_path
+    # use the CPUs this process is actually entitled to (cgroup quota), not every hardware thread
     threads = torch.get_num_threads()
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            threads = max(1, min(threads, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    torch.set_num_threads(threads)
     C_s = min(C_full, 300)
     sample = S_cpu[:C_s].clone()
     t0 = time.perf_counter()

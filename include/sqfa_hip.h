@@ -110,7 +110,7 @@ int sqfa_airm_pairwise(const void *A, int nA, const void *B, int nB, int m, int 
  * Psi (C,D,D) is read from HBM exactly once; S_c = F T_c and, in the backward pass,
  * dL/dF = sum_c (G_c + G_c^T) T_c^T need only T (C,D,K).  Psi_c is assumed symmetric
  * (covariance / second-moment matrices).
- *   F (K,D) row-major, Psi (C,D,D), T_out (C,D,K) row-major; float32, D % 4 == 0, K <= 64
+ *   F (K,D) row-major, Psi (C,D,D), T_out (C,D,K) row-major; float32 or float64, D % 4 == 0, K <= 64
  *   (SQFA_ERR_UNSUPPORTED_M otherwise: the caller keeps its own path for those shapes).
  */
 int sqfa_project_scatters(const void *F, int K, int D, const void *Psi, int C, int dtype, void *T_out,

@@ -178,10 +178,11 @@ def generalized_eigenvalues_raw(A, B):
 
 
 def native_projection_supported(scatters, filters):
-    """The streaming kernel handles float32 (C,D,D) scatters on the GPU with D % 4 == 0 and up
-    to 64 filters; anything else keeps the plain torch expression."""
+    """The streaming kernel handles float32/float64 (C,D,D) scatters on the GPU with D % 4 == 0
+    and up to 64 filters; anything else keeps the plain torch expression."""
     return (
-        scatters.is_cuda and filters.is_cuda and scatters.dtype == torch.float32 and filters.dtype == torch.float32
+        scatters.is_cuda and filters.is_cuda and scatters.dtype in (torch.float32, torch.float64)
+        and filters.dtype == scatters.dtype
         and scatters.dim() == 3 and filters.dim() == 2 and scatters.shape[-1] % 4 == 0
         and filters.shape[0] <= 64 and filters.shape[0] <= filters.shape[1]
         and scatters.shape[-1] == scatters.shape[-2] == filters.shape[1] and not scatters.requires_grad
@@ -216,9 +217,10 @@ class ProjectScatters(torch.autograd.Function):
     def backward(ctx, gS):
         (T,) = ctx.saved_tensors
         sym = gS + gS.transpose(1, 2)
-        C, D, K = T.shape
-        # (K, C*K) @ (C*K, D)
-        gF = torch.matmul(sym.permute(1, 0, 2).reshape(K, C * K), T.permute(0, 2, 1).reshape(C * K, D))
+        # per-class (K,K)@(K,D) products, then the sum over classes.  (One flat GEMM
+        # (K, C*K)@(C*K, D) is the same arithmetic but hipBLASLt is erratic for that skinny
+        # shape: 8 ms at C=1000, K=16 in isolation.)
+        gF = torch.bmm(sym, T.transpose(1, 2)).sum(dim=0)
         return gF, None
 
 

@@ -17,8 +17,8 @@
 // footprint camped on a few HBM channels when D*4 is a multiple of 4 KiB).  Component j of
 // that float4 is the B operand of MFMA j (output columns d0 + 4*i + j), the A operand is
 // F[n = l&15][k = 4s + (l>>4)], one ds_read_b32 from the F chunk staged in LDS as [k][n].
-// The C/D layout (rows n = 4*(l>>4)+reg) makes the four accumulator registers of one MFMA a
-// contiguous float4 of T[d][4q..4q+3].
+// float64 uses v_mfma_f64_16x16x4_f64 with 2 columns per lane (same 16-byte loads) and that
+// instruction's own C/D row map (row = (l>>4) + 4*reg).
 #include <hip/hip_runtime.h>
 
 #include <utility>
@@ -32,35 +32,60 @@ std::vector<std::pair<hipEvent_t, hipEvent_t>>& sqfa_project_events();  // sqfa_
 namespace sqfa {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f64x2 = __attribute__((ext_vector_type(2))) double;
+using f64x4 = __attribute__((ext_vector_type(4))) double;
 
-template <int NB, int KC>
-__global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ F, const float* __restrict__ Psi,
-                                                      float* __restrict__ T, int C, int D, int K) {
-  __shared__ float s_f[2][KC][16 * NB];  // F chunk, double buffered: [buf][k][n]
+// per-dtype pieces: the 16-byte load (VW elements), the exact MFMA, and the C/D row map
+template <typename T> struct ProjTraits;
+template <> struct ProjTraits<float> {
+  using Vec = f32x4;
+  using Acc = f32x4;
+  static constexpr int VW = 4;
+  static __device__ __forceinline__ Acc mfma(float a, float b, Acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int acc_row(int q, int reg) { return 4 * q + reg; }  // v_mfma_f32_16x16x4_f32
+};
+template <> struct ProjTraits<double> {
+  using Vec = f64x2;
+  using Acc = f64x4;
+  static constexpr int VW = 2;
+  static __device__ __forceinline__ Acc mfma(double a, double b, Acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int acc_row(int q, int reg) { return q + 4 * reg; }  // v_mfma_f64_16x16x4_f64
+};
+
+template <typename T, int NB, int KC>
+__global__ __launch_bounds__(256) void project_kernel(const T* __restrict__ F, const T* __restrict__ Psi,
+                                                      T* __restrict__ Tout, int C, int D, int K) {
+  using Tr = ProjTraits<T>;
+  using Vec = typename Tr::Vec;
+  using Acc = typename Tr::Acc;
+  constexpr int VW = Tr::VW, SW = 16 * VW;  // stripe width (columns per wave)
+  __shared__ T s_f[2][KC][16 * NB];  // F chunk, double buffered: [buf][k][n]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r16 = lane & 15, q = lane >> 4;
   const int c = blockIdx.y;
-  const int nstripes = (D + 63) / 64;
+  const int nstripes = (D + SW - 1) / SW;
   const int stripe = blockIdx.x * 4 + wave;
   const bool active = stripe < nstripes;  // idle waves still help staging F
-  int dcol = stripe * 64 + 4 * r16;
-  if (dcol > D - 4) dcol = D - 4;          // clamped columns are computed and thrown away
-  const float* __restrict__ pc = Psi + (size_t)c * D * D + dcol;
+  int dcol = stripe * SW + VW * r16;
+  if (dcol > D - VW) dcol = D - VW;        // clamped columns are computed and thrown away
+  const T* __restrict__ pc = Psi + (size_t)c * D * D + dcol;
   const int nchunks = (D + KC - 1) / KC;
 
   auto stage = [&](int chunk, int buf) {
     for (int e = tid; e < KC * 16 * NB; e += 256) {
       const int n = e % (16 * NB), kk = e / (16 * NB);
       const int k = chunk * KC + kk;
-      s_f[buf][kk][n] = (n < K && k < D) ? F[(size_t)n * D + k] : 0.f;
+      s_f[buf][kk][n] = (n < K && k < D) ? F[(size_t)n * D + k] : T(0);
     }
   };
 
-  f32x4 acc[NB][4];
+  Acc acc[NB][VW];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[nb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < VW; ++j)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) acc[nb][j][reg] = T(0);
 
   stage(0, 0);
   __syncthreads();
@@ -73,39 +98,48 @@ __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ 
       for (int s = 0; s < KC / 4; ++s) {
         int k = kbase + 4 * s + q;
         if (k > D - 1) k = D - 1;  // past the end: F is zero there, any finite row will do
-        const f32x4 b = *reinterpret_cast<const f32x4*>(pc + (size_t)k * D);
+        const Vec b = *reinterpret_cast<const Vec*>(pc + (size_t)k * D);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-          const float a = s_f[buf][4 * s + q][nb * 16 + r16];
-          acc[nb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.x, acc[nb][0], 0, 0, 0);
-          acc[nb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.y, acc[nb][1], 0, 0, 0);
-          acc[nb][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.z, acc[nb][2], 0, 0, 0);
-          acc[nb][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.w, acc[nb][3], 0, 0, 0);
+          const T a = s_f[buf][4 * s + q][nb * 16 + r16];
+#pragma unroll
+          for (int j = 0; j < VW; ++j) acc[nb][j] = Tr::mfma(a, b[j], acc[nb][j]);
         }
       }
     }
     __syncthreads();
   }
   if (!active) return;
-  // acc[nb][j][reg] = T^T[n = 16 nb + 4q + reg][d = stripe*64 + 4*r16 + j]
-  const int d0 = stripe * 64 + 4 * r16;
+  // acc[nb][j][reg] = T^T[n = 16 nb + acc_row(q, reg)][d = stripe*SW + VW*r16 + j]
+  const int d0 = stripe * SW + VW * r16;
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
-    const int n0 = nb * 16 + 4 * q;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < VW; ++j) {
       const int d = d0 + j;
       if (d < D) {
-        float* out = T + ((size_t)c * D + d) * K + n0;
-        if (n0 + 3 < K && (K % 4) == 0) {
-          *reinterpret_cast<f32x4*>(out) = acc[nb][j];
-        } else {
+        T* out = Tout + ((size_t)c * D + d) * K;
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg)
-            if (n0 + reg < K) out[reg] = acc[nb][j][reg];
+        for (int reg = 0; reg < 4; ++reg) {
+          const int n = nb * 16 + Tr::acc_row(q, reg);
+          if (n < K) out[n] = acc[nb][j][reg];
         }
       }
     }
+  }
+}
+
+template <typename T>
+static void launch_project(const T* f, const T* p, T* t, int C, int D, int K, hipStream_t stream) {
+  constexpr int SW = 16 * ProjTraits<T>::VW;
+  const dim3 grid(((D + SW - 1) / SW + 3) / 4, C, 1), block(256);
+  const int nb = (K + 15) / 16;
+  constexpr int S = sizeof(T) / 4;  // keep the LDS chunk at the float32 byte size
+  switch (nb) {
+    case 1: hipLaunchKernelGGL((project_kernel<T, 1, 128 / S>), grid, block, 0, stream, f, p, t, C, D, K); break;
+    case 2: hipLaunchKernelGGL((project_kernel<T, 2, 64 / S>), grid, block, 0, stream, f, p, t, C, D, K); break;
+    case 3: hipLaunchKernelGGL((project_kernel<T, 3, 32 / S>), grid, block, 0, stream, f, p, t, C, D, K); break;
+    default: hipLaunchKernelGGL((project_kernel<T, 4, 32 / S>), grid, block, 0, stream, f, p, t, C, D, K); break;
   }
 }
 
@@ -116,12 +150,7 @@ extern "C" int sqfa_project_scatters(const void* F, int K, int D, const void* Ps
   using namespace sqfa;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (F == nullptr || Psi == nullptr || T_out == nullptr || K < 1 || D < 4 || C < 1) return SQFA_ERR_BAD_ARGUMENT;
-  if (dtype != SQFA_F32 || (D % 4) != 0 || K > 64 || K > D) return SQFA_ERR_UNSUPPORTED_M;
-  const dim3 grid(((D + 63) / 64 + 3) / 4, C, 1), block(256);
-  const float* f = static_cast<const float*>(F);
-  const float* p = static_cast<const float*>(Psi);
-  float* t = static_cast<float*>(T_out);
-  const int nb = (K + 15) / 16;
+  if ((dtype != SQFA_F32 && dtype != SQFA_F64) || (D % 4) != 0 || K > 64 || K > D) return SQFA_ERR_UNSUPPORTED_M;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   const bool prof = sqfa_profile_enabled();
   if (prof) {
@@ -129,12 +158,10 @@ extern "C" int sqfa_project_scatters(const void* F, int K, int D, const void* Ps
     (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, stream);
   }
-  switch (nb) {
-    case 1: hipLaunchKernelGGL((project_kernel<1, 128>), grid, block, 0, stream, f, p, t, C, D, K); break;
-    case 2: hipLaunchKernelGGL((project_kernel<2, 64>), grid, block, 0, stream, f, p, t, C, D, K); break;
-    case 3: hipLaunchKernelGGL((project_kernel<3, 32>), grid, block, 0, stream, f, p, t, C, D, K); break;
-    default: hipLaunchKernelGGL((project_kernel<4, 32>), grid, block, 0, stream, f, p, t, C, D, K); break;
-  }
+  if (dtype == SQFA_F32)
+    launch_project(static_cast<const float*>(F), static_cast<const float*>(Psi), static_cast<float*>(T_out), C, D, K, stream);
+  else
+    launch_project(static_cast<const double*>(F), static_cast<const double*>(Psi), static_cast<double*>(T_out), C, D, K, stream);
   if (prof) {
     (void)hipEventRecord(e1, stream);
     sqfa_project_events().emplace_back(e0, e1);

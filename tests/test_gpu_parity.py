@@ -252,6 +252,11 @@ def test_streaming_projection_vs_torch(C, D, K):
     (W.float().to(DEV) * S).sum().backward()
     assert rel_err(S.detach().cpu(), S64.detach().reshape(C, K, K)) < 2e-6
     assert rel_err(Fg.grad.cpu(), F64.grad) < 2e-6
-    # unsupported shapes fall back (D not a multiple of 4, float64)
+    # unsupported shapes fall back (D not a multiple of 4)
     assert _native.project_scatters(Pg[:, :D - 1, :D - 1].contiguous(), Fg[:, :D - 1].detach().contiguous()) is None
-    assert _native.project_scatters(Psi.to(DEV), F.to(DEV)) is None
+    # float64 kernel (v_mfma_f64_16x16x4_f64)
+    Fd = F.to(DEV).requires_grad_(True)
+    Sd = _native.project_scatters(Psi.to(DEV), Fd)
+    (W.to(DEV) * Sd).sum().backward()
+    assert rel_err(Sd.detach().cpu(), S64.detach().reshape(C, K, K)) < 1e-13
+    assert rel_err(Fd.grad.cpu(), F64.grad) < 1e-13
