@@ -188,8 +188,8 @@ def cpu_baseline(S_cpu, scale, C_full, seconds_budget=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -323,7 +323,7 @@ def main():
         if not args.no_closure and world == 1 and dtype == torch.float32:
             del S, grad
             torch.cuda.empty_cache()
-            result["closure"] = closure_benchmark(C, D, K, model, device, max(10, args.steps // 2), lib)
+            result["closure"] = closure_benchmark(C, D, K, model, device, max(10, min(100, args.steps // 2)), lib)
             result["closure"]["roofline"]["traffic"] = pmc_traffic("project_kernel", args.workload, args.dtype)
             result["closure"]["roofline"]["traffic_unit"] = "bytes per launch (profiles/r1_pmc_c3.json)"
         if not args.no_cpu_baseline and world == 1:
