@@ -362,6 +362,27 @@ def g6():
     np.savez_compressed(os.path.join(HERE, "g6_fit_c2.npz"), **out)
 
 
+def g7():
+    """Full float64 fit of the reference on the c5-shaped configuration (CIFAR-100-shaped:
+    C=100, n_dim=3072, n_filters=16, feature_noise=0.01, SQFA, fit_pca init)."""
+    import time as _t
+    out = {}
+    torch.set_default_dtype(torch.float64)
+    stats = c2_statistics(C=100, D=3072)
+    out["check_cov00"] = stats["covariances"][0, :4, :4].numpy()
+    model = sqfa.model.SQFA(n_dim=3072, n_filters=16, feature_noise=0.01).double()
+    model.fit_pca(data_statistics=stats)
+    out["sqfa_init"] = model.filters.detach().numpy().copy()
+    t0 = _t.time()
+    loss, _t_ = model.fit(data_statistics=stats, max_epochs=300, show_progress=False, return_loss=True)
+    out["sqfa_seconds"] = np.array(_t.time() - t0)
+    out["sqfa_loss"] = loss.numpy()
+    out["sqfa_filters"] = model.filters.detach().numpy()
+    print("c5 sqfa epochs", len(loss), "seconds", float(out["sqfa_seconds"]), flush=True)
+    torch.set_default_dtype(torch.float32)
+    np.savez_compressed(os.path.join(HERE, "g7_fit_c5.npz"), **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g1x", "g2", "g3", "g4", "g5"]
     for name in which:
