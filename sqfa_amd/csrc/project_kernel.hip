@@ -12,8 +12,8 @@
 // Decomposition (T^T = F Psi, using Psi = Psi^T): a wave owns a stripe of 64 consecutive
 // columns d of one class and all K (padded to 16*NB) filters; it walks DOWN the rows k of Psi.
 // Per step every lane loads ONE float4: lane l reads Psi[k = 4s + (l>>4)][d0 + 4*(l&15) .. +3],
-// so a wave reads 4 rows x 256 contiguous bytes and the 4 waves of a workgroup (adjacent
-// stripes) read 4 rows x 1 KiB -- long contiguous runs whatever the row pitch (a 16-row x 64-B
+// so a wave reads 4 rows x 256 contiguous bytes and the WAVES (4/8/16) waves of a workgroup
+// (adjacent stripes) read 4 rows x WAVES*256 B -- long contiguous runs whatever the row pitch (a 16-row x 64-B
 // footprint camped on a few HBM channels when D*4 is a multiple of 4 KiB).  Component j of
 // that float4 is the B operand of MFMA j (output columns d0 + 4*i + j), the A operand is
 // F[n = l&15][k = 4s + (l>>4)], one ds_read_b32 from the F chunk staged in LDS as [k][n].
@@ -52,8 +52,8 @@ template <> struct ProjTraits<double> {
   static __device__ __forceinline__ int acc_row(int q, int reg) { return q + 4 * reg; }  // v_mfma_f64_16x16x4_f64
 };
 
-template <typename T, int NB, int KC>
-__global__ __launch_bounds__(256) void project_kernel(const T* __restrict__ F, const T* __restrict__ Psi,
+template <typename T, int NB, int KC, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void project_kernel(const T* __restrict__ F, const T* __restrict__ Psi,
                                                       T* __restrict__ Tout, int C, int D, int K) {
   using Tr = ProjTraits<T>;
   using Vec = typename Tr::Vec;
@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256) void project_kernel(const T* __restrict__ F, c
   const int r16 = lane & 15, q = lane >> 4;
   const int c = blockIdx.y;
   const int nstripes = (D + SW - 1) / SW;
-  const int stripe = blockIdx.x * 4 + wave;
+  constexpr int NT = 64 * WAVES;
+  const int stripe = blockIdx.x * WAVES + wave;
   const bool active = stripe < nstripes;  // idle waves still help staging F
   int dcol = stripe * SW + VW * r16;
   if (dcol > D - VW) dcol = D - VW;        // clamped columns are computed and thrown away
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void project_kernel(const T* __restrict__ F, c
   const int nchunks = (D + KC - 1) / KC;
 
   auto stage = [&](int chunk, int buf) {
-    for (int e = tid; e < KC * 16 * NB; e += 256) {
+    for (int e = tid; e < KC * 16 * NB; e += NT) {
       const int n = e % (16 * NB), kk = e / (16 * NB);
       const int k = chunk * KC + kk;
       s_f[buf][kk][n] = (n < K && k < D) ? F[(size_t)n * D + k] : T(0);
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void project_kernel(const T* __restrict__ F, c
       for (int s = 0; s < KC / 4; ++s) {
         int k = kbase + 4 * s + q;
         if (k > D - 1) k = D - 1;  // past the end: F is zero there, any finite row will do
-        const Vec b = *reinterpret_cast<const Vec*>(pc + (size_t)k * D);
+        const Vec b = __builtin_nontemporal_load(reinterpret_cast<const Vec*>(pc + (size_t)k * D));
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           const T a = s_f[buf][4 * s + q][nb * 16 + r16];
@@ -129,18 +130,31 @@ __global__ __launch_bounds__(256) void project_kernel(const T* __restrict__ F, c
   }
 }
 
-template <typename T>
-static void launch_project(const T* f, const T* p, T* t, int C, int D, int K, hipStream_t stream) {
+template <typename T, int WV>
+static void launch_project_w(const T* f, const T* p, T* t, int C, int D, int K, hipStream_t stream) {
   constexpr int SW = 16 * ProjTraits<T>::VW;
-  const dim3 grid(((D + SW - 1) / SW + 3) / 4, C, 1), block(256);
+  const dim3 grid(((D + SW - 1) / SW + WV - 1) / WV, C, 1), block(64 * WV);
   const int nb = (K + 15) / 16;
   constexpr int S = sizeof(T) / 4;  // keep the LDS chunk at the float32 byte size
   switch (nb) {
-    case 1: hipLaunchKernelGGL((project_kernel<T, 1, 128 / S>), grid, block, 0, stream, f, p, t, C, D, K); break;
-    case 2: hipLaunchKernelGGL((project_kernel<T, 2, 64 / S>), grid, block, 0, stream, f, p, t, C, D, K); break;
-    case 3: hipLaunchKernelGGL((project_kernel<T, 3, 32 / S>), grid, block, 0, stream, f, p, t, C, D, K); break;
-    default: hipLaunchKernelGGL((project_kernel<T, 4, 32 / S>), grid, block, 0, stream, f, p, t, C, D, K); break;
+    case 1: hipLaunchKernelGGL((project_kernel<T, 1, 128 / S, WV>), grid, block, 0, stream, f, p, t, C, D, K); break;
+    case 2: hipLaunchKernelGGL((project_kernel<T, 2, 64 / S, WV>), grid, block, 0, stream, f, p, t, C, D, K); break;
+    case 3: hipLaunchKernelGGL((project_kernel<T, 3, 32 / S, WV>), grid, block, 0, stream, f, p, t, C, D, K); break;
+    default: hipLaunchKernelGGL((project_kernel<T, 4, 32 / S, WV>), grid, block, 0, stream, f, p, t, C, D, K); break;
   }
+}
+
+// Workgroup width: the waves of a workgroup read adjacent stripes, i.e. WV*256 contiguous bytes
+// of 4 consecutive rows per step.  Measured on MI355X (tools/time_variants_proj.py): throughput
+// grows with the contiguous run (1 wave 2.2 TB/s, 4 waves 3.8-6.1, 16 waves = whole 3 KiB rows
+// at D=784: 4.6-5.2) until a class needs several workgroups anyway, where narrower ones balance better.
+template <typename T>
+static void launch_project(const T* f, const T* p, T* t, int C, int D, int K, hipStream_t stream) {
+  constexpr int SW = 16 * ProjTraits<T>::VW;
+  const int nstripes = (D + SW - 1) / SW;
+  if (nstripes <= 16) launch_project_w<T, 16>(f, p, t, C, D, K, stream);
+  else if (nstripes <= 32) launch_project_w<T, 8>(f, p, t, C, D, K, stream);
+  else launch_project_w<T, 4>(f, p, t, C, D, K, stream);
 }
 
 }  // namespace sqfa
