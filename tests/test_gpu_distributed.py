@@ -1,0 +1,76 @@
+"""Two ranks sharing cuda:0 over gloo (a one-GPU rehearsal of the multi-GPU path with the REAL
+HIP backend): tile shards + the fused all-reduce buffer written by the kernel (PairShard),
+and the class-sharded projection (ClassShard).  On a multi-GPU node the same code runs with
+backend "nccl" (RCCL) and one device per rank (bench.py --gpus N)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import model_cases as mc
+        from sqfa_amd import _native, distances
+        from sqfa_amd.parallel import ClassShard, PairShard
+        dev = torch.device("cuda:0")
+        G1 = load_golden("g1_airm_self.npz")
+        shard = PairShard()
+        out = {}
+        for dtype, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            S = torch.tensor(G1["C37_m16_S"], dtype=dtype, device=dev, requires_grad=True)
+            loss, flags = _native.PairwiseLoss.apply(S, 1.0, distances.EPSILON, True, -1.0 / 666, shard.shard, shard.reduce)
+            loss.backward()
+            out[tag] = (loss.item(), S.grad.cpu().numpy(), flags.tolist())
+        stats = mc.fit_stats("syn", torch.float64, dev)
+        lo, hi = (0, 10) if rank == 0 else (10, 20)
+        local = {k: v[lo:hi].clone() for k, v in stats.items()}
+        model = mc.make_model("sqfa", 50, 2, 1e-3, "sphere", torch.float64, dev)
+        model.pair_shard = shard
+        model.class_shard = ClassShard(hi - lo)
+        model.fit_pca(data_statistics=local)
+        fl, _ = model.fit(data_statistics=local, max_epochs=3, show_progress=False, return_loss=True)
+        q.put((rank, out, fl.numpy(), model.filters.detach().cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_on_one_gpu_match_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=500) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    G1 = load_golden("g1_airm_self.npz")
+    G4 = load_golden("g4_fit.npz")
+    (_, o0, fl0, F0), (_, o1, fl1, F1) = results
+    for tag, ltol, gtol in (("f64", 1e-11, 1e-8), ("f32", 1e-5, 5e-5)):
+        l0, g0, f0 = o0[tag]
+        l1, g1, f1 = o1[tag]
+        assert l0 == l1 and np.array_equal(g0, g1) and f0 == f1 == [0, 0]        # identical on both ranks
+        ref_l = float(G1["C37_m16_loss_f64"])
+        assert abs(l0 - ref_l) < ltol * abs(ref_l)
+        assert np.linalg.norm(g0 - G1["C37_m16_grad_f64"]) < gtol * np.linalg.norm(G1["C37_m16_grad_f64"])
+    assert np.array_equal(F0, F1)
+    assert np.abs(fl0 - G4["syn_sqfa_K2_e3_loss"]).max() < 1e-6
+    assert np.linalg.norm(F0 - G4["syn_sqfa_K2_e3_filters"]) < 1e-7 * np.linalg.norm(F0)
