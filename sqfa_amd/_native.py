@@ -1,9 +1,10 @@
 """torch <-> C-ABI glue for the pairwise SPD-distance kernels.
 
 torch is used for device memory, streams and autograd bookkeeping only; all arithmetic of
-the hot path happens inside libsqfa_hip.so.  Tests may install a different *pair backend*
-(``set_pair_backend``) to exercise the host logic without a GPU; the default backend is
-the HIP library and it refuses CPU tensors.
+the hot path happens inside libsqfa_hip.so.  The single call site of the library is
+``hip_pair_backend`` (bound to the module attribute ``_pair_backend`` that the autograd
+functions call through); it refuses CPU tensors and there is no other implementation in
+this package.
 """
 import ctypes
 
@@ -90,16 +91,6 @@ def hip_pair_backend(A, B, *, scale, eps, sqrt_mode, weights, uniform_weight, sh
 
 
 _pair_backend = hip_pair_backend
-
-
-def set_pair_backend(fn):
-    """Install a different pair backend (tests only).  Pass None to restore the HIP one."""
-    global _pair_backend
-    _pair_backend = hip_pair_backend if fn is None else fn
-
-
-def pair_backend():
-    return _pair_backend
 
 
 # ------------------------------------------------------------------------------------------

@@ -1,6 +1,6 @@
 """Test infrastructure: a pair backend with the signature of sqfa_amd._native.hip_pair_backend
-that evaluates the pairs with the float64 closed-form ORACLE on the CPU.  Installed with
-sqfa_amd._native.set_pair_backend() by CPU tests to exercise the host logic (model shell,
+that evaluates the pairs with the float64 closed-form ORACLE on the CPU.  Substituted for the module attribute
+sqfa_amd._native._pair_backend by CPU tests to exercise the host logic (model shell,
 fitting loop, tile sharding + all-reduce) without a GPU.  Never used by the product."""
 import ctypes
 

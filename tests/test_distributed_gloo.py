@@ -26,7 +26,7 @@ def _worker(rank, world, port, q):
         from oracle_backend import oracle_pair_backend
         from sqfa_amd import _native, distances
         from sqfa_amd.parallel import PairShard
-        _native.set_pair_backend(oracle_pair_backend)
+        _native._pair_backend = oracle_pair_backend   # test-only substitution
         G1 = load_golden("g1_airm_self.npz")
         S = torch.tensor(G1["C37_m16_S"])
         P = 37 * 36 // 2

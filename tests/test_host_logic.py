@@ -14,9 +14,10 @@ from oracle_backend import oracle_pair_backend
 @pytest.fixture(autouse=True)
 def _oracle_backend():
     from sqfa_amd import _native
-    _native.set_pair_backend(oracle_pair_backend)
+    saved = _native._pair_backend
+    _native._pair_backend = oracle_pair_backend   # test-only substitution of the module attribute
     yield
-    _native.set_pair_backend(None)
+    _native._pair_backend = saved
 
 
 CPU = torch.device("cpu")
