@@ -1,24 +1,32 @@
 // pair_kernel.hpp -- the pairwise affine-invariant distance tile kernel for gfx950.
 //
-// One workgroup (4 wave64) owns a TI x TJ tile of (A class, B class) pairs.  Inside a
+// One workgroup (WAVES wave64) owns a TI x TJ tile of (A class, B class) pairs.  Inside a
 // wave, G adjacent lanes co-operate on one pair ("lane group"); a wave therefore works
-// on 64/G pairs at once, all sharing the same B class j (so L_j^-1 is wave-uniform and
-// is fetched through the scalar cache), with TI = 64/G different A classes i.
+// on 64/G pairs at once, all sharing the same B class j (its L_j^-1 is staged once per
+// wave-round in LDS and read as broadcasts), with TI = 64/G different A classes i.
 //
 // Per pair (A = S_i, B = S_j = L_j L_j^T):
 //   1. X = L_j^-1 L_i                  (lower triangular; M = X X^T = L_j^-1 A L_j^-T)
 //   2. one-sided (Hestenes) Jacobi on the COLUMNS of X, held in registers: each lane owns
 //      CPL column slots of all MR rows; rotations between columns of one lane are local,
-//      rotations between lanes use an XOR tournament (lane^s, slot^t) through DPP.
+//      rotations between lanes follow an XOR tournament (lane^s, slot^t); partner columns
+//      travel half through DPP (2 VALU issue slots per move on gfx950) and half through
+//      ds_swizzle (the otherwise idle LDS crossbar).
 //      On exit X J = Y with orthogonal columns y_k = sigma_k v_k: lambda_k = |y_k|^2 are
 //      the generalized eigenvalues of (A,B), v_k the eigenvectors of M.
 //   3. d2 = scale * sum log(lambda)^2, D = sqrt(d2+eps) | d2
 //   4. backward (closed form, SURVEY.md 3.4 / oracle/closed_form.py): with
 //      u~_k = L_j^-T y_k:  dL/dA += sum_k (g_k/lambda_k) u~ u~^T,  dL/dB -= sum_k g_k u~ u~^T,
 //      g_k = w * dD/dd2 * scale * 2 log(lambda_k)/lambda_k.
-//      A-side sums are kept per wave in LDS (private, deterministic), B-side sums are
-//      reduced over the whole wave (all its pairs share j).  Tiles flush lower triangles
-//      to a slab in HBM; a second kernel reduces slabs per class in a fixed order.
+//      Lower triangles only, reduced with transposing tree reductions: A-side sums over the
+//      lane group go to a per-wave private LDS accumulator (deterministic), B-side sums
+//      over the whole wave (all its pairs share j) go straight to the slab in HBM.  Tiles
+//      flush the A side to the slab; finalize_kernel reduces slabs per class in a fixed order.
+//
+// Cost model behind the choices (tools/ubench/*.hip, MI355X): plain VALU op = 1 issue slot
+// (~2.5 cycles/wave-instr at >= 2 waves/SIMD, 5.4 for a lone wave), DPP op = 2 slots,
+// v_rsq/v_rcp/v_sqrt = 4 slots, v_pk_fma_f32 = 2 slots for 2 flops, ds_swizzle ~2.3 cycles
+// per CU (LDS pipe, off the VALU), ds_bpermute ~6.
 //
 // Replaces: src/sqfa/linalg.py:19-70,144-162, src/sqfa/distances.py:46-89,177-237,
 // src/sqfa/_optim.py:16-30,88-96 of the reference and the autograd backward of that chain.
