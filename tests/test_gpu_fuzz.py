@@ -1,0 +1,71 @@
+"""Randomised shape sweep of the C-ABI entry point against the float64 closed-form oracle:
+self and cross mode, ragged class counts around the tile edges of every geometry, uniform and
+per-pair weights, sqrt and squared distances, float32 and float64, 1..3 shards."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import closed_form
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def spd(rng, n, m):
+    X = rng.standard_normal((n, 2 * m + 3, m))
+    return np.einsum("cnm,cnk->cmk", X, X) / (2 * m + 3) + 0.05 * np.eye(m)
+
+
+CASES = []
+_rng = np.random.default_rng(2025)
+for m in (1, 2, 3, 4, 5, 7, 8, 9, 13, 16, 17, 20, 31, 32, 33, 41, 48, 57, 64):
+    for _ in range(2):
+        self_mode = bool(_rng.integers(0, 2))
+        nA = int(_rng.integers(2, 40 if m <= 17 else 14))
+        nB = 0 if self_mode else int(_rng.integers(1, 30 if m <= 17 else 10))
+        CASES.append((m, nA, nB, bool(_rng.integers(0, 2)), bool(_rng.integers(0, 2)), int(_rng.integers(1, 4)),
+                      int(_rng.integers(0, 2))))
+
+
+@pytest.mark.parametrize("m,nA,nB,sqrt_mode,weighted,shards,f64", CASES)
+def test_random_case(m, nA, nB, sqrt_mode, weighted, shards, f64):
+    from sqfa_amd import _native
+    rng = np.random.default_rng(1000 * m + 10 * nA + nB)
+    dtype = torch.float64 if f64 else torch.float32
+    A = spd(rng, nA, m)
+    B = None if nB == 0 else spd(rng, nB, m)
+    nBe = nA if B is None else nB
+    W = rng.standard_normal((nA, nBe)) if weighted else None
+    scale = 0.5 if m % 2 else 1.0
+    Wref = W if W is not None else np.full((nA, nBe), 0.37)
+    if B is None and W is not None:
+        Wref = np.tril(W + W.T, -1)
+    D_ref, gA_ref, gB_ref = closed_form.pairwise(A, B, Wref, scale, sqrt_mode)
+    mask = np.tril(np.ones((nA, nBe), bool), -1) if B is None else np.ones((nA, nBe), bool)
+    loss_ref = (Wref * D_ref)[mask].sum()
+    At = torch.tensor(A, dtype=dtype, device=DEV)
+    Bt = None if B is None else torch.tensor(B, dtype=dtype, device=DEV)
+    Wt = None if W is None else torch.tensor(W, dtype=dtype, device=DEV)
+    loss = 0.0
+    gA = torch.zeros_like(At)
+    gB = None if Bt is None else torch.zeros_like(Bt)
+    D = torch.zeros(nA, nBe, dtype=dtype, device=DEV)
+    for r in range(shards):
+        out = _native.hip_pair_backend(At, Bt, scale=scale, eps=1e-6, sqrt_mode=sqrt_mode, weights=Wt,
+                                       uniform_weight=0.37, shard=(r, shards), want_loss=True, want_grad=True,
+                                       want_dist=True, want_eig=False)
+        assert out["nonfinite"].tolist() == [0, 0]
+        loss += out["loss"].item()
+        gA += out["gradA"]
+        if gB is not None:
+            gB += out["gradB"]
+        if shards == 1:
+            D = out["dist"]
+    ltol, gtol = (1e-10, 1e-8) if f64 else (2e-5, 2e-4)
+    assert abs(loss - loss_ref) <= ltol * max(1.0, np.abs(Wref * D_ref)[mask].sum())
+    assert rel_err(gA.cpu(), gA_ref) <= gtol
+    if gB is not None:
+        assert rel_err(gB.cpu(), gB_ref) <= gtol
+    if shards == 1:
+        assert np.abs(D.cpu().numpy() - D_ref).max() <= (1e-9 if f64 else 5e-5) * max(1.0, D_ref.max())
