@@ -342,7 +342,7 @@ struct PairCfg {
   static constexpr int STATIC_G = sizeof(T) == 4 ? SQFA_STATIC_G : 4;
   // register budget: waves per SIMD the kernel is compiled for (256-thread blocks)
   static constexpr int XREGS = CPL * MR * (int)(sizeof(T) / 4);
-  static constexpr int MIN_WAVES = XREGS <= 72 ? 4 : (XREGS <= 170 ? 2 : 1);
+  static constexpr int MIN_WAVES = XREGS <= 72 ? 4 : (XREGS <= 100 ? 3 : (XREGS <= 170 ? 2 : 1));
   static_assert(G * CPL >= MR, "not enough column slots");
   static_assert(TJ % WAVES == 0, "TJ must be a multiple of the wave count");
 };
