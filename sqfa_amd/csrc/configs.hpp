@@ -10,9 +10,9 @@
   X(float, 8, 1, 8, 8, 4)    \
   X(float, 16, 4, 4, 8, 4)  \
   X(float, 17, 4, 5, 8, 4)  \
-  X(float, 32, 8, 4, 4, 2)   \
-  X(float, 33, 8, 5, 4, 2)   \
-  X(float, 48, 16, 3, 4, 2)  \
+  X(float, 32, 8, 4, 4, 1)   \
+  X(float, 33, 8, 5, 4, 1)   \
+  X(float, 48, 16, 3, 4, 1)  \
   X(float, 64, 32, 2, 4, 2)
 
 #define SQFA_CONFIGS_F64(X)  \
@@ -20,7 +20,7 @@
   X(double, 8, 2, 4, 8, 4)   \
   X(double, 16, 8, 2, 8, 4)  \
   X(double, 17, 8, 3, 8, 4)  \
-  X(double, 32, 16, 2, 4, 2) \
-  X(double, 33, 16, 3, 4, 2) \
-  X(double, 48, 32, 2, 4, 2) \
+  X(double, 32, 16, 2, 4, 1) \
+  X(double, 33, 16, 3, 4, 1) \
+  X(double, 48, 32, 2, 4, 1) \
   X(double, 64, 64, 1, 4, 2)
