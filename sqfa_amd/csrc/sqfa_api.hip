@@ -299,8 +299,8 @@ int sqfa_airm_profile_read(double* tile_kernel_ms_total, int* launches) {
       total += ms;
       ++n;
     }
-    hipEventDestroy(ev.a);
-    hipEventDestroy(ev.b);
+    (void)hipEventDestroy(ev.a);
+    (void)hipEventDestroy(ev.b);
   }
   g_events.clear();
   if (tile_kernel_ms_total) *tile_kernel_ms_total = total;
@@ -317,8 +317,8 @@ int sqfa_project_profile_read(double* kernel_ms_total, int* launches) {
       total += ms;
       ++n;
     }
-    hipEventDestroy(ev.first);
-    hipEventDestroy(ev.second);
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
   }
   sqfa_project_events().clear();
   if (kernel_ms_total) *kernel_ms_total = total;
@@ -429,13 +429,13 @@ int sqfa_airm_pairwise(const void* A, int nA, const void* B, int nB, int m, int 
   // K1: pair tiles
   EventPair ev{};
   if (g_profile) {
-    hipEventCreate(&ev.a);
-    hipEventCreate(&ev.b);
-    hipEventRecord(ev.a, stream);
+    (void)hipEventCreate(&ev.a);
+    (void)hipEventCreate(&ev.b);
+    (void)hipEventRecord(ev.a, stream);
   }
   e = g.launch(p, stream);
   if (g_profile) {
-    hipEventRecord(ev.b, stream);
+    (void)hipEventRecord(ev.b, stream);
     g_events.push_back(ev);
   }
   if (e != hipSuccess) return fail(SQFA_ERR_LAUNCH, "pair_tile_kernel", e);
