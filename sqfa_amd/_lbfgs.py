@@ -1,0 +1,163 @@
+"""L-BFGS with a vectorised two-loop recursion.
+
+Same algorithm, defaults, state handling and stopping rules as ``torch.optim.LBFGS`` (the
+optimizer the reference uses, src/sqfa/_optim.py:78-82) for ``line_search_fn=None``; the only
+change is HOW the search direction ``d = -H g`` is evaluated.  torch walks the history with two
+Python loops -- about ``4 * history_size`` tiny vector operations per iteration, which is
+launch-bound on a GPU and dispatch-bound on the host for the small parameter of SQFA.  Here the
+history lives in two ``(h, n)`` buffers ``S`` (steps) and ``Y`` (gradient differences) plus the
+small matrix ``SY[i, j] = s_i . y_j``, and the two loops become two triangular solves:
+
+    first loop   (newest -> oldest)  al_i = rho_i s_i.(q0 - sum_{j>i} al_j y_j)
+                 <=>  triu(SY) al = S q0                      (diag(SY) = 1/rho)
+    second loop  (oldest -> newest)  c_i = al_i - rho_i y_i.(r0 + sum_{j<i} c_j s_j)
+                 <=>  tril(SY^T) c = diag(SY) al - Y r0
+    d = r0 + S^T c,   q = q0 - Y^T al,   r0 = H_diag q,   q0 = -g
+
+i.e. four (h, n) matrix-vector products and two h x h solves per iteration: identical in exact
+arithmetic, different only in floating-point summation order.  With a line search the class
+defers to ``torch.optim.LBFGS.step``.
+"""
+import torch
+
+
+class _History:
+    """Ring buffers for the (s, y) pairs; `slots` lists the ring rows in chronological order."""
+
+    def __init__(self, size, like):
+        n = like.numel()
+        self.size = size
+        self.S = like.new_zeros(size, n)
+        self.Y = like.new_zeros(size, n)
+        self.SY = like.new_zeros(size, size)
+        self.slots = []
+
+    def push(self, y, s):
+        if len(self.slots) == self.size:
+            slot = self.slots.pop(0)  # the oldest pair is overwritten
+        else:
+            slot = len(self.slots)
+        self.slots.append(slot)
+        self.S[slot] = s
+        self.Y[slot] = y
+        self.SY[slot, :] = self.Y @ s   # s_new . y_j
+        self.SY[:, slot] = self.S @ y   # s_i . y_new
+
+    def direction(self, flat_grad, H_diag):
+        q0 = flat_grad.neg()
+        k = len(self.slots)
+        if k == 0:
+            return q0 * H_diag
+        idx = torch.as_tensor(self.slots, device=flat_grad.device)
+        SY = self.SY.index_select(0, idx).index_select(1, idx)  # chronological k x k
+        b0 = (self.S @ q0).index_select(0, idx)
+        al = torch.linalg.solve_triangular(torch.triu(SY), b0.unsqueeze(1), upper=True).squeeze(1)
+        al_ring = torch.zeros(self.size, dtype=al.dtype, device=al.device).index_copy_(0, idx, al)
+        q = q0 - self.Y.t() @ al_ring
+        r0 = q * H_diag
+        rhs = torch.diagonal(SY) * al - (self.Y @ r0).index_select(0, idx)
+        c = torch.linalg.solve_triangular(torch.tril(SY.t()), rhs.unsqueeze(1), upper=False).squeeze(1)
+        c_ring = torch.zeros(self.size, dtype=c.dtype, device=c.device).index_copy_(0, idx, c)
+        return r0 + self.S.t() @ c_ring
+
+
+class CompactLBFGS(torch.optim.LBFGS):
+    """Drop-in for torch.optim.LBFGS (same constructor)."""
+
+    @torch.no_grad()
+    def step(self, closure):
+        group = self.param_groups[0]
+        if group["line_search_fn"] is not None:
+            return super().step(closure)
+        closure = torch.enable_grad()(closure)
+        lr = float(group["lr"])
+        max_iter = group["max_iter"]
+        max_eval = group["max_eval"]
+        tolerance_grad = group["tolerance_grad"]
+        tolerance_change = group["tolerance_change"]
+        history_size = group["history_size"]
+
+        state = self.state[self._params[0]]
+        state.setdefault("func_evals", 0)
+        state.setdefault("n_iter", 0)
+
+        orig_loss = closure()
+        loss = float(orig_loss.detach())
+        current_evals = 1
+        state["func_evals"] += 1
+
+        flat_grad = self._gather_flat_grad()
+        opt_cond = flat_grad.abs().max() <= tolerance_grad
+        if opt_cond:
+            return orig_loss
+
+        d = state.get("d")
+        t = state.get("t")
+        hist = state.get("history")
+        H_diag = state.get("H_diag")
+        prev_flat_grad = state.get("prev_flat_grad")
+        prev_loss = state.get("prev_loss")
+
+        n_iter = 0
+        while n_iter < max_iter:
+            n_iter += 1
+            state["n_iter"] += 1
+
+            if state["n_iter"] == 1:
+                d = flat_grad.neg()
+                hist = _History(history_size, flat_grad)
+                H_diag = 1
+            else:
+                y = flat_grad.sub(prev_flat_grad)
+                s = d.mul(t)
+                ys = y.dot(s)
+                if ys > 1e-10:
+                    hist.push(y, s)
+                    H_diag = ys / y.dot(y)
+                d = hist.direction(flat_grad, H_diag)
+
+            if prev_flat_grad is None:
+                prev_flat_grad = flat_grad.clone(memory_format=torch.contiguous_format)
+            else:
+                prev_flat_grad.copy_(flat_grad)
+            prev_loss = loss
+
+            if state["n_iter"] == 1:
+                t = min(1.0, 1.0 / flat_grad.abs().sum()) * lr
+            else:
+                t = lr
+
+            gtd = flat_grad.dot(d)
+            if gtd > -tolerance_change:
+                break
+
+            ls_func_evals = 0
+            self._add_grad(t, d)
+            if n_iter != max_iter:
+                with torch.enable_grad():
+                    loss = float(closure().detach())
+                flat_grad = self._gather_flat_grad()
+                opt_cond = flat_grad.abs().max() <= tolerance_grad
+                ls_func_evals = 1
+
+            current_evals += ls_func_evals
+            state["func_evals"] += ls_func_evals
+
+            if n_iter == max_iter:
+                break
+            if current_evals >= max_eval:
+                break
+            if opt_cond:
+                break
+            if d.mul(t).abs().max() <= tolerance_change:
+                break
+            if abs(loss - prev_loss) < tolerance_change:
+                break
+
+        state["d"] = d
+        state["t"] = t
+        state["history"] = hist
+        state["H_diag"] = H_diag
+        state["prev_flat_grad"] = prev_flat_grad
+        state["prev_loss"] = prev_loss
+        return orig_loss

@@ -1,8 +1,9 @@
 """LBFGS driver for the SQFA models (reference: src/sqfa/_optim.py).
 
-torch.optim.LBFGS is used unmodified, so epoch semantics are the reference's by
-construction (the loss recorded for an epoch is that of the first closure call of the
-step).  What changes is the closure body: when the model's ``distance_fun``
+The optimizer is torch.optim.LBFGS' algorithm with identical control flow and state (either
+torch's class itself or the vectorised CompactLBFGS subclass, sqfa_amd/_lbfgs.py), so epoch
+semantics are the reference's (the loss recorded for an epoch is that of the first closure
+call of the step).  What changes is the closure body: when the model's ``distance_fun``
 is one of the native affine-invariant operators the closure issues ONE fused
 loss+gradient launch (no (C,C) matrix, no tril gather, validity flag read with the loss)
 instead of the reference's distance-matrix -> guard -> gather -> mean chain.
@@ -31,6 +32,12 @@ def __dir__():
 # slower than the GPU launches on an oversubscribed host.
 HOST_SIDE_LBFGS = True
 HOST_SIDE_LBFGS_MAX_NUMEL = 32768
+HOST_SIDE_LBFGS_MAX_NUMEL_COMPACT = 8192
+HOST_SIDE_LBFGS_THREADS = 4  # intra-op threads while the optimizer state lives on the host
+# Use sqfa_amd._lbfgs.CompactLBFGS (torch.optim.LBFGS with the two-loop recursion evaluated as
+# two triangular solves: ~15 instead of ~400 vector operations per iteration).  False selects
+# torch.optim.LBFGS itself.
+COMPACT_LBFGS = True
 
 _NAN_MSG = "Some distances between classes are NaN. Try using float64 or a different regularization parameter."
 _INF_MSG = "Some distances between classes are inf. Try using float64 or a different regularization parameter."
@@ -66,13 +73,20 @@ def fitting_loop(model, data_statistics, max_epochs=200, lr=0.1, atol=1e-6, show
     consecutive epochs), messages and return value as the reference's fitting_loop
     (src/sqfa/_optim.py:33-145); extra keyword arguments go to torch.optim.LBFGS."""
     device_params = list(model.parameters())
+    # the compact form is four (history x n) matrix-vector products per iteration: on the host
+    # only while they are a fraction of a millisecond, otherwise on the device
+    host_limit = HOST_SIDE_LBFGS_MAX_NUMEL_COMPACT if COMPACT_LBFGS else HOST_SIDE_LBFGS_MAX_NUMEL
     use_host = (HOST_SIDE_LBFGS and len(device_params) > 0 and all(p.is_cuda for p in device_params)
-                and sum(p.numel() for p in device_params) <= HOST_SIDE_LBFGS_MAX_NUMEL)
+                and sum(p.numel() for p in device_params) <= host_limit)
     if use_host:
         opt_params = [torch.nn.Parameter(p.detach().cpu().clone()) for p in device_params]
     else:
         opt_params = device_params
-    optimizer = torch.optim.LBFGS(opt_params, lr=lr, **kwargs)
+    if COMPACT_LBFGS:
+        from ._lbfgs import CompactLBFGS
+        optimizer = CompactLBFGS(opt_params, lr=lr, **kwargs)
+    else:
+        optimizer = torch.optim.LBFGS(opt_params, lr=lr, **kwargs)
 
     def push_parameters():
         if use_host:
@@ -114,23 +128,30 @@ def fitting_loop(model, data_statistics, max_epochs=200, lr=0.1, atol=1e-6, show
     start = time.time()
     previous = 0.0
     streak = 0
-    for epoch in tqdm(range(max_epochs), desc="Epochs", unit="epoch", disable=not show_progress):
-        value = optimizer.step(closure).item()
-        times.append(time.time() - start)
-        losses.append(value)
-        streak = streak + 1 if abs(previous - value) < atol else 0
-        previous = value
-        if streak >= 3:
-            tqdm.write(
-                f"Loss change below {atol} for 3 consecutive epochs. "
-                f"Stopping training at epoch {epoch + 1}/{max_epochs}."
+    saved_threads = torch.get_num_threads()
+    if use_host:
+        torch.set_num_threads(min(saved_threads, HOST_SIDE_LBFGS_THREADS))
+    try:
+        for epoch in tqdm(range(max_epochs), desc="Epochs", unit="epoch", disable=not show_progress):
+            value = optimizer.step(closure).item()
+            times.append(time.time() - start)
+            losses.append(value)
+            streak = streak + 1 if abs(previous - value) < atol else 0
+            previous = value
+            if streak >= 3:
+                tqdm.write(
+                    f"Loss change below {atol} for 3 consecutive epochs. "
+                    f"Stopping training at epoch {epoch + 1}/{max_epochs}."
+                )
+                break
+        else:
+            print(
+                f"Reached max_epochs ({max_epochs}) without meeting stopping criteria."
+                + "Consider increasing max_epochs, changing initialization or using dtype=torch.float64."
             )
-            break
-    else:
-        print(
-            f"Reached max_epochs ({max_epochs}) without meeting stopping criteria."
-            + "Consider increasing max_epochs, changing initialization or using dtype=torch.float64."
-        )
+    finally:
+        if use_host:
+            torch.set_num_threads(saved_threads)
     push_parameters()  # the values LBFGS ended on
     if return_loss:
         return torch.tensor(losses), torch.tensor(times)
