@@ -339,10 +339,10 @@ struct PairCfg {
 #ifndef SQFA_STATIC_G
 #define SQFA_STATIC_G 8
 #endif
-  static constexpr int STATIC_G = sizeof(T) == 4 ? SQFA_STATIC_G : 4;
+  static constexpr int STATIC_G = SQFA_STATIC_G;
   // register budget: waves per SIMD the kernel is compiled for (256-thread blocks)
   static constexpr int XREGS = CPL * MR * (int)(sizeof(T) / 4);
-  static constexpr int MIN_WAVES = XREGS <= 72 ? 4 : (XREGS <= 100 ? 3 : (XREGS <= 170 ? 2 : 1));
+  static constexpr int MIN_WAVES = sizeof(T) == 8 ? (XREGS <= 140 ? 2 : 1) : (XREGS <= 72 ? 4 : (XREGS <= 100 ? 3 : (XREGS <= 170 ? 2 : 1)));
   static_assert(G * CPL >= MR, "not enough column slots");
   static_assert(TJ % WAVES == 0, "TJ must be a multiple of the wave count");
 };
