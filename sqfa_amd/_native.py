@@ -133,7 +133,9 @@ class PairwiseLoss(torch.autograd.Function):
     def forward(ctx, S, scale, eps, sqrt_mode, weight, shard, reducer):
         extra = {}
         fused = None
-        if reducer is not None and shard[1] > 1 and _pair_backend is hip_pair_backend:
+        owner = getattr(reducer, "__self__", None)
+        if (reducer is not None and shard[1] > 1 and _pair_backend is hip_pair_backend
+                and hasattr(owner, "reduce_fused")):
             # the kernel writes loss and gradient straight into the all-reduce buffer
             # [loss, nan, inf, grad...]: no packing copies
             fused = torch.empty(S.numel() + 3, dtype=S.dtype, device=S.device)
@@ -143,7 +145,7 @@ class PairwiseLoss(torch.autograd.Function):
                             want_dist=False, want_eig=False, **extra)
         loss, nonfinite, grad = out["loss"], out["nonfinite"], out["gradA"]
         if fused is not None:
-            loss, nonfinite, grad = reducer.__self__.reduce_fused(fused, nonfinite, S.shape)
+            loss, nonfinite, grad = owner.reduce_fused(fused, nonfinite, S.shape)
         elif reducer is not None:
             loss, nonfinite, grad = reducer(loss, nonfinite, grad)
         ctx.save_for_backward(grad)
