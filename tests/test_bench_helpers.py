@@ -1,0 +1,46 @@
+"""CPU checks of bench.py's workload generator and CPU-baseline leg (no GPU needed)."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_workload_generator_matches_explicit_projection():
+    C, D, K = 5, 40, 4
+    S, scale = bench.make_feature_scatters(C, D, K, "smsqfa", torch.device("cpu"), torch.float64)
+    assert S.shape == (C, K, K) and scale == 1.0
+    # explicit restatement: Sigma_c = A A^T + 0.05 I, Psi = Sigma + mu mu^T, S = F Psi F^T + 0.01 I
+    gen = torch.Generator().manual_seed(1234)
+    R = min(D, 128)
+    F = torch.randn(K, D, generator=torch.Generator().manual_seed(7), dtype=torch.float64)
+    F = F / F.norm(dim=1, keepdim=True)
+    A = torch.randn(C, D, R, generator=gen, dtype=torch.float32).double() / R ** 0.5
+    mu = 0.1 * torch.randn(C, D, generator=gen, dtype=torch.float32).double()
+    Psi = A @ A.transpose(1, 2) + 0.05 * torch.eye(D, dtype=torch.float64) + mu[:, :, None] * mu[:, None, :]
+    expect = F @ Psi @ F.T + 0.01 * torch.eye(K, dtype=torch.float64)
+    assert torch.allclose(S, expect, atol=1e-12)
+    E, scale = bench.make_feature_scatters(C, D, K, "sqfa", torch.device("cpu"), torch.float64)
+    assert E.shape == (C, K + 1, K + 1) and scale == 0.5
+    assert torch.linalg.eigvalsh(E).min() > 0
+
+
+def test_cpu_baseline_leg_runs_the_oracle():
+    S, scale = bench.make_feature_scatters(12, 30, 3, "smsqfa", torch.device("cpu"), torch.float32)
+    out = bench.cpu_baseline(S, scale, 12, seconds_budget=0.5)
+    assert out["kind"] == "port" and out["unit"] == "evals/s" and out["value"] > 0 and out["cores"] >= 1
+    json.dumps(out)
+
+
+def test_pmc_summary_is_consistent():
+    with open(os.path.join(ROOT, "profiles", "r1_pmc_c3.json")) as fh:
+        pmc = json.load(fh)["kernels"]
+    assert abs(pmc["project_kernel"]["algorithmic_bytes_per_launch"] - 4 * 1000 * 784 * 784) < 1
+    assert 0.9 < pmc["project_kernel"]["hbm_bytes_per_launch"] / pmc["project_kernel"]["algorithmic_bytes_per_launch"] < 1.3
+    assert np.isfinite(pmc["pair_tile_kernel"]["hbm_bytes_per_launch"])
