@@ -51,7 +51,18 @@ struct PairParams {
   int shard_index, shard_count;
   int nbi, nbj;
   double scale, eps, uniform_weight;
+  float scale_f, eps_f, uniform_weight_f;  // the same three, pre-rounded for the float32 kernels (stay in SGPRs)
 };
+
+template <typename T> __device__ __forceinline__ T param_scale(const PairParams& p) {
+  if constexpr (sizeof(T) == 4) return p.scale_f; else return p.scale;
+}
+template <typename T> __device__ __forceinline__ T param_eps(const PairParams& p) {
+  if constexpr (sizeof(T) == 4) return p.eps_f; else return p.eps;
+}
+template <typename T> __device__ __forceinline__ T param_uniform_weight(const PairParams& p) {
+  if constexpr (sizeof(T) == 4) return p.uniform_weight_f; else return p.uniform_weight;
+}
 
 __host__ __device__ constexpr int pow2ceil(int v) {
   int p = 1;
@@ -139,18 +150,55 @@ template <int S, typename T> __device__ __forceinline__ T lane_xor_row(T v, int 
   return lane_xor<S>(v, s);
 }
 
+// gfx950 row swaps: v_permlane{16,32}_swap exchange the odd H-lane rows of the first operand
+// with the even H-lane rows of the second.  For a value `a` wanted by the lanes with bit H
+// clear and `b` wanted by the lanes with bit H set, (a', b') = swap(a, b) gives
+//   a' + b' = a[lane] + a[lane ^ H]  where bit H is clear,  b[lane] + b[lane ^ H]  where it is set
+// -- one exchange step of a transposing reduction in two instructions, no selects.
+template <int H> __device__ __forceinline__ int row_swap_sum_i(int a, int b, int& other) {
+  static_assert(H == 16 || H == 32, "row swaps exist for 16 and 32 lanes");
+  if constexpr (H == 16) {
+    auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    other = r[1];
+    return r[0];
+  } else {
+    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    other = r[1];
+    return r[0];
+  }
+}
+template <int H> __device__ __forceinline__ float row_swap_sum(float a, float b) {
+  int o;
+  const int k = row_swap_sum_i<H>(__builtin_bit_cast(int, a), __builtin_bit_cast(int, b), o);
+  return __builtin_bit_cast(float, k) + __builtin_bit_cast(float, o);
+}
+template <int H> __device__ __forceinline__ double row_swap_sum(double a, double b) {
+  int ohi, olo;
+  const int khi = row_swap_sum_i<H>(__double2hiint(a), __double2hiint(b), ohi);
+  const int klo = row_swap_sum_i<H>(__double2loint(a), __double2loint(b), olo);
+  return __hiloint2double(khi, klo) + __hiloint2double(ohi, olo);
+}
+
 // sum over the G lanes of a lane group (every lane gets the total)
 template <int G, typename T> __device__ __forceinline__ T group_sum(T v) {
   if constexpr (G >= 2) v += dpp_mov<0xB1>(v);
   if constexpr (G >= 4) v += dpp_mov<0x4E>(v);
   if constexpr (G >= 8) v += dpp_mov<0x141>(v);   // quads are uniform now: half mirror == xor 4
   if constexpr (G >= 16) v += dpp_mov<0x140>(v);  // row mirror == xor 8
-  if constexpr (G >= 32) v += __shfl_xor(v, 16, 64);
-  if constexpr (G >= 64) v += __shfl_xor(v, 32, 64);
+  if constexpr (G >= 32) v = row_swap_sum<16>(v, v);
+  if constexpr (G >= 64) v = row_swap_sum<32>(v, v);
   return v;
 }
 // sum over all 64 lanes, fixed association order (deterministic)
 template <typename T> __device__ __forceinline__ T wave_sum(T v) { return group_sum<64>(v); }
+// tell the compiler that a value is the same in every lane (moves it to SGPRs)
+__device__ __forceinline__ float wave_uniform(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ double wave_uniform(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                          __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 
 // ---------------------------------------------------------------------------------------
 // Jacobi rotation parameters for "my" column (squared norm no) against a partner column
@@ -249,11 +297,18 @@ __device__ __forceinline__ void cross_rounds_static(T (&x)[CPL][MR], T (&nrm)[CP
 // indices selected by its own bit and hands the other half to its partner, so the work
 // halves per level (~2 cross-lane adds per index in total) and lane l of the block ends with
 // the finished sum of index BASE + l -- ready for a conflict-free LDS update / coalesced store.
-template <int D, typename T> __device__ __forceinline__ T xor_fetch(T v) {
+__device__ __forceinline__ float bpermute(int byte_addr, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ double bpermute(int byte_addr, double v) {
+  return __hiloint2double(__builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v)),
+                          __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v)));
+}
+template <int D, typename T> __device__ __forceinline__ T xor_fetch(T v, int lane) {
   if constexpr (D == 1) return dpp_mov<0xB1>(v);
   else if constexpr (D == 2) return dpp_mov<0x4E>(v);
   else if constexpr (D < 32) return swizzle_xor<D>(v);
-  else return __shfl_xor(v, D, 64);
+  else return bpermute((lane ^ D) << 2, v);  // the caller's lane id (not a hoisted mbcnt)
 }
 
 __host__ __device__ constexpr int tri_row(int idx) {
@@ -280,6 +335,9 @@ struct OuterProduct {
   }
 };
 
+#ifndef SQFA_SWAP_MIN
+#define SQFA_SWAP_MIN 16
+#endif
 template <int LEVEL, int BASE, typename T, typename P>
 __device__ __forceinline__ T tree_reduce(const P& prod, int lane) {
   if constexpr (LEVEL == 0) {
@@ -288,13 +346,20 @@ __device__ __forceinline__ T tree_reduce(const P& prod, int lane) {
     constexpr int H = 1 << (LEVEL - 1);
     const T a = tree_reduce<LEVEL - 1, BASE, T>(prod, lane);
     const T b = tree_reduce<LEVEL - 1, BASE + H, T>(prod, lane);
-    const bool upper = (lane & H) != 0;
-    const T keep = upper ? b : a;
-    const T send = upper ? a : b;
-    return keep + xor_fetch<H>(send);
+    if constexpr (H >= SQFA_SWAP_MIN) {
+      return row_swap_sum<H>(a, b);
+    } else {
+      const bool upper = (lane & H) != 0;
+      const T keep = upper ? b : a;
+      const T send = upper ? a : b;
+      return keep + xor_fetch<H>(send, lane);
+    }
   }
 }
 
+#ifndef SQFA_TREE_SCHED_BARRIER
+#define SQFA_TREE_SCHED_BARRIER 1
+#endif
 template <int LEVEL, int I, int N, int TRI, typename T, typename P, typename F>
 __device__ __forceinline__ void tree_reduce_blocks(const P& prod, int lane, F&& sink) {
   if constexpr (I < N) {
@@ -306,6 +371,9 @@ __device__ __forceinline__ void tree_reduce_blocks(const P& prod, int lane, F&& 
     } else {
       if (idx < TRI) sink(idx, v);
     }
+#if SQFA_TREE_SCHED_BARRIER
+    __builtin_amdgcn_sched_barrier(0);  // keep the blocks apart: interleaving them stretches live ranges into spills
+#endif
     tree_reduce_blocks<LEVEL, I + 1, N, TRI, T>(prod, lane, sink);
   }
 }
@@ -367,9 +435,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
   if (p.self_mode && (i0 + TI - 1 <= j0)) return;  // no pair with i > j in this tile
 
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int prob = lane / G, g = lane % G;
-  const int i = i0 + prob;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave id in an SGPR
   const int tile = bi * p.nbj + bj;
 
   if (p.want_grad) {
@@ -378,17 +444,27 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
   __syncthreads();
 
   const T tol2 = R::kEps * R::kEps * T(MR);
-  const T scale = T(p.scale), eps = T(p.eps);
+  const T scale = param_scale<T>(p), eps = param_eps<T>(p);
 
+  // per-wave partial results, wave-uniform so that they live in SGPRs across the sweep loop
   T loss_acc = T(0);
   int n_nan = 0, n_inf = 0;
 
-  const int ic = i < p.nA ? i : p.nA - 1;
-  const T* lt = LT + (size_t)ic * (MR * MR);
+  // The sweep loop needs nearly the whole register budget.  Everything that depends on the
+  // lane id is therefore re-derived from an opaque copy of threadIdx.x before and after it
+  // (a few integer ops) instead of being kept live across it in registers that would spill.
+  auto opaque_lane = [&]() {
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    return t & 63;
+  };
 
   for (int jj = wave; jj < TJ; jj += WAVES) {
     const int j = j0 + jj;  // wave-uniform
-    const bool valid = (i < p.nA) && (j < p.nB) && (!p.self_mode || i > j);
+    int lane = opaque_lane();
+    int g = lane % G;
+    int i = i0 + lane / G;
+    bool valid = (i < p.nA) && (j < p.nB) && (!p.self_mode || i > j);
     if (!__any(valid)) {
       if (p.want_grad) {  // nothing to add for this B class, but the slab entry must be defined
         T* gbz = static_cast<T*>(p.slab_grad) + ((size_t)tile * (TI + TJ) + TI + jj) * TRI;
@@ -396,6 +472,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
       }
       continue;
     }
+    const T* lt = LT + (size_t)(i < p.nA ? i : p.nA - 1) * (MR * MR);
     const int jc = __builtin_amdgcn_readfirstlane(j < p.nB ? j : p.nB - 1);
     T* li = s_li + wave * (MR * MR);
     {
@@ -473,6 +550,10 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
       more = __any(big);
       ++sweeps;
     }
+    lane = opaque_lane();
+    g = lane % G;
+    i = i0 + lane / G;
+    valid = (i < p.nA) && (j < p.nB) && (!p.self_mode || i > j);
     if (p.sweep_counter != nullptr && lane == 0) {
       atomicAdd(&p.sweep_counter[0], (unsigned long long)sweeps);
       atomicAdd(&p.sweep_counter[1], 1ULL);
@@ -494,23 +575,25 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
     }
     const T d2 = scale * group_sum<G>(part);
     const T dist = p.sqrt_mode ? R::sqrt_(d2 + eps) : d2;
+    const int io = i;
     T w = T(0);
     if (valid) {
       if (Wt != nullptr) {
-        w = Wt[(size_t)i * p.nB + j];
-        if (p.self_mode) w += Wt[(size_t)j * p.nB + i];
+        w = Wt[(size_t)io * p.nB + j];
+        if (p.self_mode) w += Wt[(size_t)j * p.nB + io];
       } else {
-        w = T(p.uniform_weight);
+        w = param_uniform_weight<T>(p);
       }
     }
-    if (valid && g == 0) {
-      loss_acc = R::fma_(w, dist, loss_acc);
-      n_nan += (dist != dist) ? 1 : 0;
-      n_inf += (dist == dist && !R::finite(dist)) ? 1 : 0;
+    const bool head = valid && g == 0;  // one lane per pair reports
+    loss_acc = wave_uniform(loss_acc + wave_sum(head ? w * dist : T(0)));
+    n_nan += __popcll(__ballot(head && dist != dist));
+    n_inf += __popcll(__ballot(head && dist == dist && !R::finite(dist)));
+    if (head) {
       if (p.dist_out != nullptr) {
         T* D = static_cast<T*>(p.dist_out);
-        D[(size_t)i * p.nB + j] = dist;
-        if (p.self_mode) D[(size_t)j * p.nB + i] = dist;
+        D[(size_t)io * p.nB + j] = dist;
+        if (p.self_mode) D[(size_t)j * p.nB + io] = dist;
       }
     }
     if (valid && p.eig_out != nullptr) {
@@ -519,8 +602,8 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
       for (int c = 0; c < CPL; ++c) {
         const int col = g * CPL + c;
         if (col < p.m) {
-          E[((size_t)i * p.nB + j) * p.m + col] = lam[c];
-          if (p.self_mode) E[((size_t)j * p.nB + i) * p.m + col] = T(1) / lam[c];
+          E[((size_t)io * p.nB + j) * p.m + col] = lam[c];
+          if (p.self_mode) E[((size_t)j * p.nB + io) * p.m + col] = T(1) / lam[c];
         }
       }
     }
@@ -557,25 +640,20 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
       //   B side: over all 64 lanes (every pair of the wave shares j); lane l finishes entries
       //           idx = 64*i + l and stores them to the slab (this wave is the only writer)
       {
-        T* ga = s_ga + (size_t)(wave * TI + prob) * TRIP;
+        const int lo = lane;
+        T* ga = s_ga + (size_t)(wave * TI + lo / G) * TRIP;
         const OuterProduct<T, MR, CPL> prodA{x, coefA};
         constexpr int LG = ilog2(G);
-        tree_reduce_blocks<LG, 0, (TRI + G - 1) / G, TRI, T>(prodA, lane, [&](int idx, T v) { ga[idx] += v; });
+        tree_reduce_blocks<LG, 0, (TRI + G - 1) / G, TRI, T>(prodA, lo, [&](int idx, T v) { ga[idx] += v; });
         T* gb = static_cast<T*>(p.slab_grad) + ((size_t)tile * (TI + TJ) + TI + jj) * TRI;
         const OuterProduct<T, MR, CPL> prodB{x, coefB};
-        tree_reduce_blocks<6, 0, (TRI + 63) / 64, TRI, T>(prodB, lane, [&](int idx, T v) { gb[idx] = v; });
+        tree_reduce_blocks<6, 0, (TRI + 63) / 64, TRI, T>(prodB, lo, [&](int idx, T v) { gb[idx] = v; });
       }
     }
   }
 
   // ---- tile epilogue: flush to the slab ------------------------------------------------
-  loss_acc = wave_sum(loss_acc);
-#pragma unroll
-  for (int sh = 1; sh < 64; sh <<= 1) {
-    n_nan += __shfl_xor(n_nan, sh, 64);
-    n_inf += __shfl_xor(n_inf, sh, 64);
-  }
-  if (lane == 0) {
+  if ((tid & 63) == 0) {
     s_red[wave] = loss_acc;
     s_redi[2 * wave] = n_nan;
     s_redi[2 * wave + 1] = n_inf;

@@ -395,6 +395,9 @@ int sqfa_airm_pairwise(const void* A, int nA, const void* B, int nB, int m, int 
   p.scale = scale;
   p.eps = eps;
   p.uniform_weight = uniform_weight;
+  p.scale_f = (float)scale;
+  p.eps_f = (float)eps;
+  p.uniform_weight_f = (float)uniform_weight;
 
   // K0: factors
   auto launch_chol = [&](auto zero, const void* src, int n, void* lt, void* li) {

@@ -1,0 +1,57 @@
+"""Turn two rocprofv3 PMC passes into profiles/<name>.json (HBM bytes per launch per kernel).
+
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_w -o w --output-format csv -- python3 tools/run_closure_once.py
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_f -o f --output-format csv -- python3 tools/run_closure_once.py
+    python tools/pmc_summary.py gpurun_out/pmc_w/w_counter_collection.csv gpurun_out/pmc_f/f_counter_collection.csv profiles/r1_pmc_c3.json
+
+Counters are KiB per dispatch.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE
+counts half of the bytes of wide coalesced streaming reads, so it is doubled for project_kernel
+(16 B/lane streaming loads); the pair kernel's reads are narrow broadcast loads and stay uncorrected.
+"""
+import collections
+import csv
+import json
+import sys
+
+C, D, K = 1000, 784, 16  # workload of tools/run_closure_once.py (c3)
+KERNELS = ("project_kernel", "cholesky_kernel", "pair_tile_kernel", "finalize_kernel")
+
+
+def averages(path):
+    acc = collections.defaultdict(list)
+    with open(path) as fh:
+        for row in csv.DictReader(fh):
+            for k in KERNELS:
+                if k in row["Kernel_Name"]:
+                    acc[k].append(float(row["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def main(write_csv, fetch_csv, out):
+    wr, fe = averages(write_csv), averages(fetch_csv)
+    kernels = {k: {"FETCH_SIZE_KiB": fe[k], "WRITE_SIZE_KiB": wr[k]} for k in KERNELS}
+    pj = kernels["project_kernel"]
+    pj["hbm_bytes_per_launch"] = (2 * pj["FETCH_SIZE_KiB"] + pj["WRITE_SIZE_KiB"]) * 1024
+    pj["algorithmic_bytes_per_launch"] = 4 * C * D * D
+    pr = kernels["pair_tile_kernel"]
+    pr["hbm_bytes_per_launch"] = (pr["FETCH_SIZE_KiB"] + pr["WRITE_SIZE_KiB"]) * 1024
+    pr["algorithmic_bytes_per_launch"] = 4 * (2 * C * K * K + 1)
+    pr["note"] = (
+        "traffic = the slab of the deterministic two-pass reduction (4032 tiles x 24 lower triangles x 136 x 4 B "
+        "= 52.6 MB written here, read back by finalize_kernel) + the L/Linv factors; no register spills"
+    )
+    doc = {
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace) on "
+        "tools/run_closure_once.py (c3 closure: C=1000, D=784, K=16, f32), MI355X; counters are in KiB per dispatch",
+        "correction": "gfx950: FETCH_SIZE counts 1/2 of the bytes of wide coalesced streaming reads "
+        "(MI355X_MICROARCH.md, HBM) -> doubled for project_kernel (16 B/lane streaming loads); the pair kernel's "
+        "reads are narrow broadcast loads and uncalibrated -> reported uncorrected",
+        "kernels": kernels,
+    }
+    with open(out, "w") as fh:
+        json.dump(doc, fh, indent=1)
+    print(json.dumps({k: v.get("hbm_bytes_per_launch") for k, v in kernels.items()}))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
