@@ -9,6 +9,7 @@ loss+gradient launch (no (C,C) matrix, no tril gather, validity flag read with t
 instead of the reference's distance-matrix -> guard -> gather -> mean chain.
 """
 import time
+import warnings
 
 import torch
 from tqdm import tqdm
@@ -38,6 +39,17 @@ HOST_SIDE_LBFGS_THREADS = 4  # intra-op threads while the optimizer state lives 
 # two triangular solves: ~15 instead of ~400 vector operations per iteration).  False selects
 # torch.optim.LBFGS itself.
 COMPACT_LBFGS = True
+
+# Closure latency.  After GRAPH_WARMUP_CLOSURES eager evaluations the
+# fused closure (parametrization -> projection -> pairwise loss+gradient -> backward to the raw
+# filters -> packing of [loss, nan, inf, grad]) is captured once in a HIP graph; every later
+# closure is ONE graph launch plus ONE device-to-host copy instead of ~40 launches and a trip
+# through the autograd engine.  Shapes are static within a fitting_loop call; data-dependent
+# errors are reported through the flags, which are read on the host after the replay.  Only
+# the single-process fused path is captured (no collectives inside the graph).  If the capture
+# fails the loop warns once and continues eagerly -- same arithmetic either way.
+GRAPH_CLOSURE = True
+GRAPH_WARMUP_CLOSURES = 3
 
 _NAN_MSG = "Some distances between classes are NaN. Try using float64 or a different regularization parameter."
 _INF_MSG = "Some distances between classes are inf. Try using float64 or a different regularization parameter."
@@ -99,29 +111,79 @@ def fitting_loop(model, data_statistics, max_epochs=200, lr=0.1, atol=1e-6, show
         raise ValueError("At least two classes are needed to fit the filters.")
     rows, cols = torch.tril_indices(n_classes, n_classes, offset=-1)
 
-    def closure():
-        optimizer.zero_grad()
-        push_parameters()
-        if use_host:
-            for p in device_params:
-                p.grad = None
+    def evaluate():
+        """Enqueue loss and gradient on the device: (loss, flags or None); no host sync."""
         fused = model._fused_closure_loss(prepared)
         if fused is not None:
             loss, flags = fused
-            raise_on_flags(flags)
         else:
             if getattr(model, "class_shard", None) is not None:
                 raise NotImplementedError("class-sharded statistics need one of the native distance operators")
             distances = model.get_class_distances(prepared, regularized=True)
             check_distances_valid(distances)
             loss = -distances[rows.to(distances.device), cols.to(distances.device)].mean()
+            flags = None
         loss.backward()
         if hasattr(model, "_sync_gradients"):
             model._sync_gradients()
+        return loss.detach(), flags
+
+    def pack(loss, flags):
+        """[loss, nan, inf, grad...] in one device tensor: a single copy brings it to the host."""
+        dtype = loss.dtype
+        head = [loss.reshape(1), flags.to(dtype) if flags is not None else loss.new_zeros(2)]
+        return torch.cat(head + [p.grad.reshape(-1).to(dtype) for p in device_params])
+
+    def unpack_to_host(packed):
+        host = packed.cpu()  # the only synchronisation of the closure
+        raise_on_flags(host[1:3].round().to(torch.int32))
+        offset = 3
+        for p, h in zip(device_params, opt_params):
+            n = p.numel()
+            h.grad = host[offset:offset + n].view_as(h).to(h.dtype)
+            offset += n
+        return host[0]
+
+    graph = {"state": "off", "calls": 0, "graph": None, "packed": None, "grads": None}
+    if (GRAPH_CLOSURE and len(device_params) > 0 and all(p.is_cuda for p in device_params)
+            and getattr(model, "pair_shard", None) is None and getattr(model, "class_shard", None) is None
+            and hasattr(model, "_has_fused_closure") and model._has_fused_closure()):
+        graph["state"] = "warmup"
+
+    def capture():
+        for p in device_params:
+            p.grad = None
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss, flags = evaluate()
+            packed = pack(loss, flags)
+        graph.update(graph=g, packed=packed, grads=[p.grad for p in device_params], state="on")
+
+    def closure():
+        push_parameters()
+        if graph["state"] == "warmup" and graph["calls"] >= GRAPH_WARMUP_CLOSURES:
+            try:
+                capture()
+            except Exception as err:  # capture is an optimisation: report and continue eagerly
+                warnings.warn(f"sqfa_amd: HIP graph capture of the closure failed ({err}); running eagerly")
+                graph["state"] = "off"
+        if graph["state"] == "on":
+            graph["graph"].replay()
+            packed = graph["packed"]
+            for p, grad in zip(device_params, graph["grads"]):
+                p.grad = grad  # the static gradient tensors the graph writes
+            if use_host:
+                return unpack_to_host(packed)
+            raise_on_flags(packed[1:3].round().to(torch.int32))
+            return packed[0].clone()  # the static buffer is overwritten by the next replay
+        graph["calls"] += 1
+        for p in device_params:
+            p.grad = None
+        loss, flags = evaluate()
         if use_host:
-            for p, h in zip(device_params, opt_params):
-                h.grad = p.grad.detach().cpu()
-            return loss.detach().cpu()
+            return unpack_to_host(pack(loss, flags))
+        if flags is not None:
+            raise_on_flags(flags)
         return loss
 
     losses, times = [], []

@@ -121,12 +121,17 @@ class SecondMomentsSQFA(nn.Module):
 
     _fused_kind = "spd"
 
+    def _has_fused_closure(self):
+        """True when distance_fun is the native operator this model's fused closure evaluates."""
+        spec = distances.fused_spec(self.distance_fun)
+        return spec is not None and spec[0] == self._fused_kind
+
     def _fused_closure_loss(self, prepared):
         """(loss, flags) through one fused loss+gradient launch, or None when the model's
         distance_fun is not a native affine-invariant operator."""
-        spec = distances.fused_spec(self.distance_fun)
-        if spec is None or spec[0] != self._fused_kind:
+        if not self._has_fused_closure():
             return None
+        spec = distances.fused_spec(self.distance_fun)
         _, scale, sqrt_mode = spec
         S = self._fused_input(prepared)
         if self.class_shard is not None:

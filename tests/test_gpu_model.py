@@ -154,3 +154,61 @@ def test_c5_config_full_fit_matches_reference_f64():
     assert len(loss) == len(ref)
     assert np.abs(loss.numpy()[:3] - ref[:3]).max() < 1e-6
     assert abs(loss[-1].item() - ref[-1]) < 1e-3 * abs(ref[-1])
+
+
+@pytest.mark.parametrize("host_lbfgs", [True, False])
+@pytest.mark.parametrize("model_name", ["smsqfa", "sqfa"])
+def test_graph_captured_closure_matches_eager(model_name, host_lbfgs, monkeypatch):
+    """The HIP-graph closure replays exactly the eager arithmetic: same
+    per-epoch losses and filters, with the optimizer state on the host and on the device."""
+    import sqfa_amd._optim as opt
+    stats = {k: v.to(DEV) for k, v in mc.c2_statistics(C=24, D=96).items()}
+    monkeypatch.setattr(opt, "HOST_SIDE_LBFGS", host_lbfgs)
+    replays = [0]
+    original_replay = torch.cuda.CUDAGraph.replay
+
+    def counting_replay(self):
+        replays[0] += 1
+        return original_replay(self)
+
+    monkeypatch.setattr(torch.cuda.CUDAGraph, "replay", counting_replay)
+    runs = {}
+    for use_graph in (False, True):
+        monkeypatch.setattr(opt, "GRAPH_CLOSURE", use_graph)
+        model = mc.make_model(model_name, 96, 4, 0.01, "sphere", torch.float64, DEV)
+        model.fit_pca(data_statistics=stats)
+        loss, _ = model.fit(data_statistics=stats, max_epochs=6, show_progress=False, return_loss=True)
+        runs[use_graph] = (loss.numpy(), model.filters.detach().cpu().numpy())
+        if not use_graph:
+            assert replays[0] == 0
+    assert replays[0] > 20, "the graph path was not taken"
+    assert np.abs(runs[True][0] - runs[False][0]).max() < 1e-12
+    assert rel_err(runs[True][1], runs[False][1]) < 1e-10
+
+
+def test_graph_captured_closure_reports_nonfinite(monkeypatch):
+    """Validity flags are read after every replay: statistics that turn indefinite AFTER the
+    capture still raise the reference's ValueError."""
+    import sqfa_amd
+    import sqfa_amd._optim as opt
+    monkeypatch.setattr(opt, "GRAPH_WARMUP_CLOSURES", 1)
+    S = mc.c2_statistics(C=6, D=12)["covariances"].to(torch.float32).to(DEV)
+    model = sqfa_amd.model.SecondMomentsSQFA(n_dim=12, feature_noise=0.0, n_filters=2).to(DEV)
+    calls = [0]
+    original = model._fused_closure_loss
+
+    def poisoned(prepared):
+        calls[0] += 1
+        return original(prepared)
+
+    model._fused_closure_loss = poisoned
+    original_replay = torch.cuda.CUDAGraph.replay
+
+    def replay_on_bad_data(self):
+        S[1].neg_()  # the captured graph reads the statistics in place
+        return original_replay(self)
+
+    monkeypatch.setattr(torch.cuda.CUDAGraph, "replay", replay_on_bad_data)
+    with pytest.raises(ValueError, match="NaN"):
+        model.fit(data_statistics=S, max_epochs=3, show_progress=False)
+    assert calls[0] >= 2  # warm-up closure + the capture

@@ -34,12 +34,28 @@ def run(name, max_epochs=300):
         calls[0] += 1
         return orig(p)
     model._fused_closure_loss = counted
+    replay = torch.cuda.CUDAGraph.replay
+    def counted_replay(self):  # closures served by the captured HIP graph
+        calls[0] += 1
+        return replay(self)
+    torch.cuda.CUDAGraph.replay = counted_replay
     torch.cuda.synchronize(); t0 = time.perf_counter()
     loss, t = model.fit(data_statistics=st, max_epochs=max_epochs, show_progress=False, return_loss=True)
     torch.cuda.synchronize(); wall = time.perf_counter() - t0
+    torch.cuda.CUDAGraph.replay = replay
     print(f"{name}: {model_name} C={C} D={D} K={K}: fit() {wall:.2f} s, {len(loss)} epochs, {calls[0]} closures "
           f"({wall/calls[0]*1e3:.2f} ms/closure), final loss {loss[-1].item():.6f}", flush=True)
 
+def warm_up():
+    """One throw-away fit so that library initialisation is not billed to the first configuration."""
+    dev = torch.device("cuda:0")
+    st = stats(10, 64, dev)
+    model = sqfa_amd.model.SQFA(n_dim=64, n_filters=2, feature_noise=0.01).to(dev)
+    model.fit_pca(data_statistics=st)
+    model.fit(data_statistics=st, max_epochs=3, show_progress=False)
+
+
 if __name__ == "__main__":
+    warm_up()
     for n in (sys.argv[1:] or ["c1", "c2", "c2s", "c5"]):
         run(n, 300 if n != "c3" else 40)
