@@ -34,32 +34,76 @@ def oas_covariance(points, assume_centered=False):
     return (1 - rho) * S + rho * target
 
 
+# padded class batches hold at most this many point-matrix elements (x2 for the centred copy)
+_BATCH_ELEMENTS = 1 << 27
+
+
 def class_statistics(points, labels, estimator="empirical"):
     """Per-class mean, covariance and second moment.  Labels are integers 0..C-1
     (reference: statistics.py:8-54; keys 'means', 'covariances', 'second_moments').
 
     The reference selects each class with a boolean mask inside a Python loop (one
-    ``nonzero`` host sync per class).  Here the points are sorted by label once (stable, so
-    every class keeps its original point order and the sums are the same), the class
-    boundaries come back in ONE host transfer, and each class is a contiguous slice."""
+    ``nonzero`` host sync and ~8 small launches per class: launch-bound for many classes).
+    Here the points are sorted by label once (stable), the class sizes come back in ONE host
+    transfer, and classes of similar size are processed together as zero-padded batches
+    ``(G, n_max, D)``: masked centring, one batched GEMM ``Xc^T Xc`` per group, batched OAS
+    shrinkage.  Same estimators (centre first, then 1/(n-1)), different summation order."""
     if estimator not in ("empirical", "oas"):
         raise ValueError("estimator must be 'empirical' or 'oas'")
     labels = labels.to(points.device)
     n_classes = int(labels.max()) + 1
     d = points.shape[-1]
     order = torch.sort(labels, stable=True).indices
-    bounds = torch.cumsum(torch.bincount(labels, minlength=n_classes), 0).tolist()
+    counts_dev = torch.bincount(labels, minlength=n_classes)
+    counts = counts_dev.tolist()
+    starts_dev = torch.cumsum(counts_dev, 0) - counts_dev
     sorted_points = points[order]
     means = points.new_zeros(n_classes, d)
     covs = points.new_zeros(n_classes, d, d)
-    start = 0
-    for c in range(n_classes):
-        pts = sorted_points[start:bounds[c]]
-        start = bounds[c]
-        means[c] = pts.mean(dim=0)
-        covs[c] = sample_covariance(pts) if estimator == "empirical" else oas_covariance(pts)
+    # groups of classes of similar size (little padding), bounded in memory
+    by_size = sorted(range(n_classes), key=lambda c: counts[c])
+    pos = 0
+    while pos < n_classes:
+        group = [by_size[pos]]
+        pos += 1
+        while pos < n_classes:
+            n_max = max(counts[by_size[pos]], 1)
+            if (len(group) + 1) * n_max * d > _BATCH_ELEMENTS or n_max > 2 * max(counts[group[0]], 16):
+                break
+            group.append(by_size[pos])
+            pos += 1
+        cls = torch.as_tensor(group, device=points.device)
+        m, c = _batched_moments(sorted_points, starts_dev[cls], counts_dev[cls], max(counts[group[-1]], 1), estimator)
+        means[cls] = m
+        covs[cls] = c
     second = covs + means[:, :, None] * means[:, None, :]
     return {"means": means, "covariances": covs, "second_moments": second}
+
+
+def _batched_moments(sorted_points, starts, counts, n_max, estimator):
+    """Mean and covariance of G classes stored contiguously in `sorted_points` (class g occupies
+    rows starts[g] .. starts[g]+counts[g]), as one zero-padded (G, n_max, D) batch."""
+    d = sorted_points.shape[-1]
+    dtype = sorted_points.dtype
+    r = torch.arange(n_max, device=sorted_points.device)
+    mask = r[None, :] < counts[:, None]                                   # (G, n_max)
+    idx = starts[:, None] + torch.minimum(r[None, :], (counts[:, None] - 1).clamp(min=0))
+    idx = idx.clamp(max=sorted_points.shape[0] - 1)
+    keep = mask[:, :, None].to(dtype)
+    batch = sorted_points[idx].mul_(keep)                                 # (G, n_max, D), zero padded
+    n = counts.to(dtype)
+    mean = batch.sum(dim=1) / n[:, None]
+    centred = batch.sub_(mean[:, None, :]).mul_(keep)                     # in place: padding stays zero
+    S = torch.bmm(centred.transpose(1, 2), centred) / (n - 1)[:, None, None]
+    if estimator == "oas":
+        # Chen et al. 2010, as oas_covariance below, per class
+        tr = torch.diagonal(S, dim1=1, dim2=2).sum(dim=1)
+        tr2 = (S * S).sum(dim=(1, 2))
+        rho = ((1 - 2 / d) * tr2 + tr * tr) / ((n + 1 - 2 / d) * (tr2 - tr * tr / d))
+        rho = torch.clamp(rho, max=1.0)
+        eye = torch.eye(d, dtype=dtype, device=S.device)
+        S = (1 - rho)[:, None, None] * S + (rho * tr / d)[:, None, None] * eye
+    return mean, S
 
 
 def pca(points, n_components=None):

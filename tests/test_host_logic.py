@@ -165,6 +165,31 @@ def test_statistics_match_reference():
         statistics.pca_from_scatter(rot, 9)
 
 
+@pytest.mark.parametrize("estimator", ["empirical", "oas"])
+@pytest.mark.parametrize("batch_elements", [1 << 27, 4000])
+def test_class_statistics_ragged_classes(estimator, batch_elements, monkeypatch):
+    """Ragged class sizes through the padded-batch path (one or many groups) against the
+    per-class definition (reference: statistics.py:8-54): centre, X^T X / (n-1), optional OAS."""
+    from sqfa_amd import statistics
+    monkeypatch.setattr(statistics, "_BATCH_ELEMENTS", batch_elements)
+    g = torch.Generator().manual_seed(3)
+    sizes = [5, 17, 200, 33, 2, 64, 65, 31, 400, 8]
+    d = 12
+    y = torch.cat([torch.full((n,), c) for c, n in enumerate(sizes)])
+    X = torch.randn(len(y), d, generator=g, dtype=torch.float64) * 2.0 + torch.randn(d, generator=g, dtype=torch.float64)
+    perm = torch.randperm(len(y), generator=g)
+    X, y = X[perm], y[perm]
+    st = statistics.class_statistics(X, y, estimator=estimator)
+    for c in range(len(sizes)):
+        pts = X[y == c]
+        cov = statistics.sample_covariance(pts) if estimator == "empirical" else statistics.oas_covariance(pts)
+        assert rel_err(st["means"][c], pts.mean(dim=0)) < 1e-13
+        assert rel_err(st["covariances"][c], cov) < 1e-12
+        assert rel_err(st["second_moments"][c], cov + torch.outer(pts.mean(dim=0), pts.mean(dim=0))) < 1e-12
+    with pytest.raises(ValueError):
+        statistics.class_statistics(X, y, estimator="ledoit")
+
+
 def test_linalg_helpers_and_shapes():
     from sqfa_amd import distances, linalg
     g5 = mc.G5
