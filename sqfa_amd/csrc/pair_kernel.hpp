@@ -11,7 +11,8 @@
 //      CPL column slots of all MR rows; rotations between columns of one lane are local,
 //      rotations between lanes follow an XOR tournament (lane^s, slot^t); partner columns
 //      travel half through DPP (2 VALU issue slots per move on gfx950) and half through
-//      ds_swizzle (the otherwise idle LDS crossbar).
+//      ds_swizzle (the otherwise idle LDS crossbar).  Columns carry a scale (x = d x^), so
+//      a rotation costs one fma per element (see cross_round).
 //      On exit X J = Y with orthogonal columns y_k = sigma_k v_k: lambda_k = |y_k|^2 are
 //      the generalized eigenvalues of (A,B), v_k the eigenvectors of M.
 //   3. d2 = scale * sum log(lambda)^2, D = sqrt(d2+eps) | d2
@@ -92,7 +93,12 @@ template <> struct Real<float> {
 template <> struct Real<double> {
   static constexpr double kEps = 2.220446049250313e-16;
   static constexpr double kEarly2 = 1.0e-15;
-  static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+  // v_rcp_f64 seed + one third-order step: 1/x = y (1 + e + e^2 + O(e^3)), e = 1 - x y
+  static __device__ __forceinline__ double rcp(double x) {
+    const double y = __builtin_amdgcn_rcp(x);
+    const double e = __builtin_fma(-x, y, 1.0);
+    return __builtin_fma(y, __builtin_fma(e, e, e), y);
+  }
   // v_rsq_f64 seed (>= 24 good bits) + one third-order correction step: with e = 1 - x y^2,
   // x^-1/2 = y (1 - e)^-1/2 = y (1 + e/2 + 3e^2/8 + O(e^3)) -- full double precision in six
   // instructions instead of the ~45 of the IEEE sqrt + divide sequences.  Only called with
@@ -249,12 +255,28 @@ __device__ __forceinline__ void rot_params(T no, T nr, T gam, T tol2, T tie, T& 
 // against the partner's ALREADY ROTATED slot c with the algebraically equivalent form
 //   x' = x/cs - tl * x_partner_new        (from x' = cs x - sn q, q = (q' - sn... ) / cs)
 // so only one MR-long temporary is live at a time.
+//
+// Scaled ("fast") rotations: column slot c holds x^ with  x_true = d[c] * x^  (id[c] = 1/d[c]).
+// A rotation x' = cs (x - tl y) then needs ONE fma per element, x^' = x^ - (tl d_y/d_x) y^,
+// with the factor cs folded into the scale (d' = d cs) -- instead of a multiply and an fma.
+// d only ever changes by factors in [1/sqrt2, sqrt2], a few hundred times: no range problem.
+#ifndef SQFA_FAST_GIVENS
+#define SQFA_FAST_GIVENS 1
+#endif
 template <typename T, int MR, int CPL, int S>
-__device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], int s, T tol2, bool& big) {
+__device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], T (&d)[CPL], T (&id)[CPL], int s, T tol2,
+                                            bool& big) {
   using R = Real<T>;
   constexpr int TP2 = pow2ceil(CPL);
   const int lane_id = (int)(threadIdx.x & 63);
   const T tie = ((lane_id ^ s) > lane_id) ? T(1) : T(-1);
+#if SQFA_FAST_GIVENS
+  // The rotation applied to the TRUE columns is orthogonal only if the two owners use
+  // consistent scales (my 1/d against the d my partner fetches): id is re-derived from d at
+  // the start of every round, so it never carries more than a few roundings of drift.
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) id[c] = R::rcp(d[c]);
+#endif
 #pragma unroll
   for (int t = 0; t < TP2; ++t) {
 #pragma unroll
@@ -268,10 +290,24 @@ __device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], int 
 #pragma unroll
       for (int r = 0; r < MR; ++r) gam1 = R::fma_(x[c][r], rv[r], gam1);
       const T nr1 = lane_xor<S>(nrm[cp], s);
+#if SQFA_FAST_GIVENS
+      const T dp = lane_xor<S>(d[cp], s);
+      gam1 *= d[c] * dp;
+#endif
       T cs1, ics1, sn1, tl1;
       rot_params(nrm[c], nr1, gam1, tol2, tie, cs1, ics1, sn1, tl1, big);
+#if SQFA_FAST_GIVENS
+      {
+        const T a = -(tl1 * dp * id[c]);
+#pragma unroll
+        for (int r = 0; r < MR; ++r) x[c][r] = R::fma_(a, rv[r], x[c][r]);
+        d[c] *= cs1;
+        id[c] *= ics1;
+      }
+#else
 #pragma unroll
       for (int r = 0; r < MR; ++r) x[c][r] = cs1 * x[c][r] - sn1 * rv[r];
+#endif
       nrm[c] -= tl1 * gam1;
       if (cp != c) {
         // my slot cp meets the partner's slot c: the partner has just evaluated exactly that
@@ -281,8 +317,21 @@ __device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], int 
         const T tl2 = -lane_xor<S>(tl1, s);
 #pragma unroll
         for (int r = 0; r < MR; ++r) rv[r] = lane_xor_row<S>(x[c][r], s, r);  // partner's slot c, rotated
+#if SQFA_FAST_GIVENS
+        {
+          // x' = x/cs - tl y_new:  d' = d/cs,  x^' = x^ - (tl d_y,new / d') y^_new
+          const T cs2 = lane_xor<S>(cs1, s);
+          const T dpn = lane_xor<S>(d[c], s);
+          d[cp] *= ics2;
+          id[cp] *= cs2;
+          const T b = -(tl2 * dpn * id[cp]);
+#pragma unroll
+          for (int r = 0; r < MR; ++r) x[cp][r] = R::fma_(b, rv[r], x[cp][r]);
+        }
+#else
 #pragma unroll
         for (int r = 0; r < MR; ++r) x[cp][r] = ics2 * x[cp][r] - tl2 * rv[r];
+#endif
         nrm[cp] -= tl2 * gam2;
       }
     }
@@ -290,10 +339,11 @@ __device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], int 
 }
 
 template <typename T, int MR, int G, int CPL, int S>
-__device__ __forceinline__ void cross_rounds_static(T (&x)[CPL][MR], T (&nrm)[CPL], T tol2, bool& big) {
+__device__ __forceinline__ void cross_rounds_static(T (&x)[CPL][MR], T (&nrm)[CPL], T (&d)[CPL], T (&id)[CPL], T tol2,
+                                                    bool& big) {
   if constexpr (S < G) {
-    cross_round<T, MR, CPL, S>(x, nrm, S, tol2, big);
-    cross_rounds_static<T, MR, G, CPL, S + 1>(x, nrm, tol2, big);
+    cross_round<T, MR, CPL, S>(x, nrm, d, id, S, tol2, big);
+    cross_rounds_static<T, MR, G, CPL, S + 1>(x, nrm, d, id, tol2, big);
   }
 }
 
@@ -516,7 +566,9 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
     }
 
     // ---- 2. one-sided Jacobi ---------------------------------------------------------
-    T nrm[CPL];
+    T nrm[CPL], d[CPL], id[CPL];  // true squared norms; column scales x_true = d x (see cross_round)
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) d[c] = id[c] = T(1);
     int sweeps = 0;
     bool more = true;
     while (more && sweeps < Cfg::MAX_SWEEPS) {
@@ -525,9 +577,13 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
         T a = T(0);
 #pragma unroll
         for (int r = 0; r < MR; ++r) a = R::fma_(x[c][r], x[c][r], a);
-        nrm[c] = a;
+        nrm[c] = a * d[c] * d[c];
       }
       bool big = false;
+#if SQFA_FAST_GIVENS
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) id[c] = R::rcp(d[c]);
+#endif
       // pairs inside my own lane
 #pragma unroll
       for (int c1 = 0; c1 < CPL; ++c1) {
@@ -536,28 +592,54 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
           T gam = T(0);
 #pragma unroll
           for (int r = 0; r < MR; ++r) gam = R::fma_(x[c1][r], x[c2][r], gam);
+#if SQFA_FAST_GIVENS
+          gam *= d[c1] * d[c2];
+#endif
           T cs, ics, sn, tl;
           rot_params(nrm[c1], nrm[c2], gam, tol2, T(1), cs, ics, sn, tl, big);
+#if SQFA_FAST_GIVENS
+          {
+            const T a1 = -(tl * d[c2] * id[c1]), a2 = tl * d[c1] * id[c2];
+#pragma unroll
+            for (int r = 0; r < MR; ++r) {
+              const T xp = x[c1][r];
+              x[c1][r] = R::fma_(a1, x[c2][r], xp);
+              x[c2][r] = R::fma_(a2, xp, x[c2][r]);
+            }
+            d[c1] *= cs;
+            d[c2] *= cs;
+            id[c1] *= ics;
+            id[c2] *= ics;
+          }
+#else
 #pragma unroll
           for (int r = 0; r < MR; ++r) {
             const T xp = x[c1][r], xq = x[c2][r];
             x[c1][r] = cs * xp - sn * xq;
             x[c2][r] = sn * xp + cs * xq;
           }
+#endif
           nrm[c1] -= tl * gam;
           nrm[c2] += tl * gam;
         }
       }
       // pairs across the lanes of my group
       if constexpr (G > 1 && G <= Cfg::STATIC_G) {
-        cross_rounds_static<T, MR, G, CPL, 1>(x, nrm, tol2, big);
+        cross_rounds_static<T, MR, G, CPL, 1>(x, nrm, d, id, tol2, big);
       } else if constexpr (G > Cfg::STATIC_G) {
 #pragma unroll 1
-        for (int s = 1; s < G; ++s) cross_round<T, MR, CPL, 0>(x, nrm, s, tol2, big);
+        for (int s = 1; s < G; ++s) cross_round<T, MR, CPL, 0>(x, nrm, d, id, s, tol2, big);
       }
       more = __any(big);
       ++sweeps;
     }
+#if SQFA_FAST_GIVENS
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+#pragma unroll
+      for (int r = 0; r < MR; ++r) x[c][r] *= d[c];  // back to the true columns
+    }
+#endif
     lane = opaque_lane();
     g = lane % G;
     i = i0 + lane / G;
@@ -661,13 +743,14 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
   }
 
   // ---- tile epilogue: flush to the slab ------------------------------------------------
-  if ((tid & 63) == 0) {
+  const int tid_end = tid;
+  if ((tid_end & 63) == 0) {
     s_red[wave] = loss_acc;
     s_redi[2 * wave] = n_nan;
     s_redi[2 * wave + 1] = n_inf;
   }
   __syncthreads();
-  if (tid == 0) {
+  if (tid_end == 0) {
     T l = T(0);
     int nn = 0, ni = 0;
     for (int wv = 0; wv < WAVES; ++wv) {
@@ -681,7 +764,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
   }
   if (p.want_grad) {
     T* slab = static_cast<T*>(p.slab_grad) + (size_t)tile * (TI + TJ) * TRI;
-    for (int k = tid; k < TI * TRI; k += NT) {
+    for (int k = tid_end; k < TI * TRI; k += NT) {
       const int pi = k / TRI, idx = k % TRI;
       T acc = T(0);
 #pragma unroll

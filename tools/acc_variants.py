@@ -1,4 +1,4 @@
-import sys, shutil, subprocess
+import os, sys, shutil, subprocess
 code = r'''
 import sys; sys.path.insert(0,'tools'); sys.path.insert(0,'.'); sys.path.insert(0,'tests')
 import torch, numpy as np, time_pairs as t
@@ -23,6 +23,7 @@ l64,g64=fused(S64); l32,g32=fused(S64.float())
 print("golden worst loss rel %.2e grad rel %.2e | baseline-like f32 vs f64: loss %.2e grad %.2e" % (worst[0], worst[1], abs(l32-l64)/abs(l64), rel_err(g32.cpu(), g64.cpu())))
 '''
 for lib in sys.argv[1:]:
-    shutil.copy(lib, "sqfa_amd/lib/libsqfa_hip.so")
+    if os.path.abspath(lib) != os.path.abspath("sqfa_amd/lib/libsqfa_hip.so"):
+        shutil.copy(lib, "sqfa_amd/lib/libsqfa_hip.so")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     print(lib, "\n".join(out.stdout.strip().splitlines()[-2:]) if out.stdout.strip() else out.stderr[-800:], flush=True)
