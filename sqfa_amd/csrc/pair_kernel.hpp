@@ -10,9 +10,10 @@
 //   2. one-sided (Hestenes) Jacobi on the COLUMNS of X, held in registers: each lane owns
 //      CPL column slots of all MR rows; rotations between columns of one lane are local,
 //      rotations between lanes follow an XOR tournament (lane^s, slot^t); partner columns
-//      travel half through DPP (2 VALU issue slots per move on gfx950) and half through
-//      ds_swizzle (the otherwise idle LDS crossbar).  Columns carry a scale (x = d x^), so
-//      a rotation costs one fma per element (see cross_round).
+//      travel through DPP (2 VALU issue slots per move on gfx950) or ds_swizzle (the
+//      otherwise idle LDS crossbar), in a ratio tuned per group size.  Columns carry a
+//      squared scale (x = sqrt(D) x^), so a rotation costs one fma per element and its
+//      parameters one v_rsq + one v_rcp (see rot_scaled).
 //      On exit X J = Y with orthogonal columns y_k = sigma_k v_k: lambda_k = |y_k|^2 are
 //      the generalized eigenvalues of (A,B), v_k the eigenvectors of M.
 //   3. d2 = scale * sum log(lambda)^2, D = sqrt(d2+eps) | d2
@@ -102,7 +103,7 @@ template <> struct Real<double> {
   // v_rsq_f64 seed (>= 24 good bits) + one third-order correction step: with e = 1 - x y^2,
   // x^-1/2 = y (1 - e)^-1/2 = y (1 + e/2 + 3e^2/8 + O(e^3)) -- full double precision in six
   // instructions instead of the ~45 of the IEEE sqrt + divide sequences.  Only called with
-  // x > 0 whenever the result is used (rot_params selects it away otherwise).
+  // x > 0 whenever the result is used (rot_scaled selects it away otherwise).
   static __device__ __forceinline__ double rsq(double x) {
     const double y = __builtin_amdgcn_rsq(x);
     const double e = __builtin_fma(-(x * y), y, 1.0);
@@ -152,14 +153,20 @@ template <int S, typename T> __device__ __forceinline__ T lane_xor(T v, int s) {
 
 // Same, for the r-th element of a column: DPP moves cost two VALU issue slots on gfx950
 // (tools/ubench/valu_rate.hip), ds_swizzle runs on the otherwise idle LDS crossbar (~2.3
-// cycles per wave-op per CU).  Every SQFA_SWZ_MOD-th row goes through the crossbar so both
-// pipes share the cross-lane traffic (0 = DPP only).
-#ifndef SQFA_SWZ_MOD
-#define SQFA_SWZ_MOD 2
+// cycles per wave-op per CU).  Of every 8 rows, SWZ go through the crossbar so that both
+// pipes share the cross-lane traffic.  Measured optimum (tools/time_variants_any.py): all
+// rows for 4-lane groups; for 8-lane groups, whose partners 4..7 can only be reached through
+// the crossbar anyway, 1 of 8 in float32 and none in float64 (two 32-bit moves per element).
+#ifndef SQFA_SWZ_ROWS_OF_8
+#define SQFA_SWZ_ROWS_OF_8 -1  // -1: by group size and element type
 #endif
-template <int S, typename T> __device__ __forceinline__ T lane_xor_row(T v, int s, int r) {
-  if constexpr (S >= 1 && S <= 3 && SQFA_SWZ_MOD > 0) {
-    if (r % SQFA_SWZ_MOD == 0) return swizzle_xor<S>(v);
+template <typename T, int G> constexpr int swizzled_rows_of_8() {
+  if (SQFA_SWZ_ROWS_OF_8 >= 0) return SQFA_SWZ_ROWS_OF_8;
+  return G <= 4 ? 8 : (sizeof(T) == 4 ? 1 : 0);
+}
+template <int S, int SWZ, typename T> __device__ __forceinline__ T lane_xor_row(T v, int s, int r) {
+  if constexpr (S >= 1 && S <= 3 && SWZ > 0) {
+    if (r % 8 < SWZ) return swizzle_xor<S>(v);
   }
   return lane_xor<S>(v, s);
 }
@@ -215,68 +222,59 @@ __device__ __forceinline__ double wave_uniform(double v) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Jacobi rotation parameters for "my" column (squared norm no) against a partner column
-// (squared norm nr) with inner product gam.  Symmetric formulation: both owners evaluate
-// this with their own (no, nr) and apply  x' = cs*x - sn*x_partner,  no' = no - tl*gam
-// (or, against an already rotated partner column, x' = ics*x - tl*x_partner_new).
-// The two owners must choose opposite signs of t; zeta = (nr-no)/(2 gam) does that by itself
-// except when the norms are EXACTLY equal (zeta = +0 on both sides): `tie` (+1 on one owner,
-// -1 on the other) breaks that tie antisymmetrically.
+// Scaled ("fast") Jacobi rotations in squared quantities.
+//
+// Column slot c holds x^ with  x_true = sqrt(D[c]) x^ ; nrm[c] = |x_true|^2 is tracked
+// separately.  For my column x (norm^2 no, scale^2 Dx) against a partner column y (nr, Dy)
+// with scaled inner product gh = <x^, y^>  (gam = gh sqrt(Dx Dy),  g2 = gam^2 = gh^2 Dx Dy):
+//   dh = (nr - no)/2,  h = sqrt(dh^2 + g2),  u = cos^2 th = (1 + |dh|/h)/2,
+//   tan th = k gam  with  k = sign(dh) / (2 h u)
+// and the rotation  x' = cos (x - tan y),  y' = cos (y + tan x)  becomes, per element, ONE fma:
+//   x^' = x^ - (k gh Dy) y^,   y^' = y^ + (k gh Dx) x^,   Dx' = u Dx,  Dy' = u Dy,
+//   no' = no - k g2,  nr' = nr + k g2
+// -- no square root of a scale is ever needed inside the sweeps (one v_rsq and one v_rcp per
+// rotation), and both owners of a cross-lane rotation work from the same Dx, Dy, gh, so the
+// rotation they jointly apply to the true columns is orthogonal to rounding.  D changes by
+// factors in [1/2, 2], a few hundred times at most: no range problem.
+//
+// The two owners must choose opposite signs; sign(dh) does that by itself except when the
+// norms are EXACTLY equal (dh = +0 on both sides): `tie` (+1 on one owner, -1 on the other)
+// breaks that tie antisymmetrically.  Outputs are the identity (u = ru = 1, k = 0) when the
+// columns are already orthogonal to working precision.
 template <typename T>
-__device__ __forceinline__ void rot_params(T no, T nr, T gam, T tol2, T tie, T& cs, T& ics, T& sn, T& tl, bool& big) {
-  // Half-angle form with two reciprocal square roots (the transcendental unit runs at a
-  // quarter of the FMA rate): with d = (nr-no)/2, h = sqrt(d^2 + gam^2):
-  //   cos 2th = |d|/h, sin 2th = sign(d) gam/h  (|th| <= pi/4)
-  //   cs = cos th = sqrt((1 + cos 2th)/2),  sn = sin th = sin 2th / (2 cs),  tl = sn/cs, ics = 1/cs
+__device__ __forceinline__ void rot_scaled(T no, T nr, T gh, T Dx, T Dy, T tol2, T tie, T& u, T& ru, T& k, T& g2,
+                                           bool& big) {
   using R = Real<T>;
   const T ab = no * nr;
-  const T g2 = gam * gam;
+  g2 = gh * gh * (Dx * Dy);
   const bool rot = g2 > tol2 * ab;
   big = big || (g2 > R::kEarly2 * ab);
-  const T d = T(0.5) * (nr - no);
-  const T rh = R::rsq(R::fma_(d, d, g2));
-  const T u = R::fma_(T(0.5) * R::abs_(d), rh, T(0.5));
-  const T rc = R::rsq(u);
-  const T sgn = d == T(0) ? tie : d;
-  const T s_ = R::copysign_(T(0.5) * R::abs_(gam * rh * rc), sgn) * R::copysign_(T(1), gam);
-  cs = rot ? u * rc : T(1);
-  ics = rot ? rc : T(1);
-  sn = rot ? s_ : T(0);
-  tl = sn * ics;
+  const T dh = T(0.5) * (nr - no);
+  const T rh = R::rsq(R::fma_(dh, dh, g2));
+  const T uu = R::fma_(T(0.5) * R::abs_(dh), rh, T(0.5));
+  const T ruu = R::rcp(uu);
+  const T sgn = dh == T(0) ? tie : dh;
+  u = rot ? uu : T(1);
+  ru = rot ? ruu : T(1);
+  k = rot ? R::copysign_(T(0.5) * rh * ruu, sgn) : T(0);
 }
 
 // one tournament round against the lane group member (lane ^ s): every column slot c of
 // mine meets slot (c ^ t) of the partner, t = 0..pow2ceil(CPL)-1.
 //
 // For t != 0 slots c and cp = c^t are handled together: pair a = (my c, partner's cp) and
-// pair b = (my cp, partner's c).  The partner evaluates the same code, so its <x_c, my x_cp>
-// is my pair-b inner product: it is fetched with one cross-lane move instead of MR FMAs.
-// Slot c is rotated first (standard form, old partner values); slot cp is rotated afterwards
-// against the partner's ALREADY ROTATED slot c with the algebraically equivalent form
-//   x' = x/cs - tl * x_partner_new        (from x' = cs x - sn q, q = (q' - sn... ) / cs)
+// pair b = (my cp, partner's c).  The partner evaluates the same code, so pair b is ITS
+// pair a: its inner product and rotation parameters are fetched with a few cross-lane moves
+// instead of being recomputed.  Slot c is rotated first (old partner values); slot cp is
+// rotated afterwards against the partner's ALREADY ROTATED slot c, with the algebraically
+// equivalent form  x' = x/cos - tan y_new, i.e.  x^' = x^ - (k gh Dy_new) y^_new,  Dx' = Dx/u,
 // so only one MR-long temporary is live at a time.
-//
-// Scaled ("fast") rotations: column slot c holds x^ with  x_true = d[c] * x^  (id[c] = 1/d[c]).
-// A rotation x' = cs (x - tl y) then needs ONE fma per element, x^' = x^ - (tl d_y/d_x) y^,
-// with the factor cs folded into the scale (d' = d cs) -- instead of a multiply and an fma.
-// d only ever changes by factors in [1/sqrt2, sqrt2], a few hundred times: no range problem.
-#ifndef SQFA_FAST_GIVENS
-#define SQFA_FAST_GIVENS 1
-#endif
-template <typename T, int MR, int CPL, int S>
-__device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], T (&d)[CPL], T (&id)[CPL], int s, T tol2,
-                                            bool& big) {
+template <typename T, int MR, int CPL, int S, int SWZ>
+__device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], int s, T tol2, bool& big) {
   using R = Real<T>;
   constexpr int TP2 = pow2ceil(CPL);
   const int lane_id = (int)(threadIdx.x & 63);
   const T tie = ((lane_id ^ s) > lane_id) ? T(1) : T(-1);
-#if SQFA_FAST_GIVENS
-  // The rotation applied to the TRUE columns is orthogonal only if the two owners use
-  // consistent scales (my 1/d against the d my partner fetches): id is re-derived from d at
-  // the start of every round, so it never carries more than a few roundings of drift.
-#pragma unroll
-  for (int c = 0; c < CPL; ++c) id[c] = R::rcp(d[c]);
-#endif
 #pragma unroll
   for (int t = 0; t < TP2; ++t) {
 #pragma unroll
@@ -285,65 +283,46 @@ __device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
       if (cp < c || cp >= CPL) continue;  // resolved at compile time after unrolling
       T rv[MR];
 #pragma unroll
-      for (int r = 0; r < MR; ++r) rv[r] = lane_xor_row<S>(x[cp][r], s, r);  // partner's slot cp
-      T gam1 = T(0);
+      for (int r = 0; r < MR; ++r) rv[r] = lane_xor_row<S, SWZ>(x[cp][r], s, r);  // partner's slot cp
+      T gh = T(0);
 #pragma unroll
-      for (int r = 0; r < MR; ++r) gam1 = R::fma_(x[c][r], rv[r], gam1);
+      for (int r = 0; r < MR; ++r) gh = R::fma_(x[c][r], rv[r], gh);
       const T nr1 = lane_xor<S>(nrm[cp], s);
-#if SQFA_FAST_GIVENS
-      const T dp = lane_xor<S>(d[cp], s);
-      gam1 *= d[c] * dp;
-#endif
-      T cs1, ics1, sn1, tl1;
-      rot_params(nrm[c], nr1, gam1, tol2, tie, cs1, ics1, sn1, tl1, big);
-#if SQFA_FAST_GIVENS
+      const T Dp = lane_xor<S>(D[cp], s);
+      T u1, ru1, k1, g21;
+      rot_scaled(nrm[c], nr1, gh, D[c], Dp, tol2, tie, u1, ru1, k1, g21, big);
+      const T kgh = k1 * gh, kg2 = k1 * g21;
       {
-        const T a = -(tl1 * dp * id[c]);
+        const T a = -(kgh * Dp);
 #pragma unroll
         for (int r = 0; r < MR; ++r) x[c][r] = R::fma_(a, rv[r], x[c][r]);
-        d[c] *= cs1;
-        id[c] *= ics1;
       }
-#else
-#pragma unroll
-      for (int r = 0; r < MR; ++r) x[c][r] = cs1 * x[c][r] - sn1 * rv[r];
-#endif
-      nrm[c] -= tl1 * gam1;
+      D[c] *= u1;
+      nrm[c] -= kg2;
       if (cp != c) {
         // my slot cp meets the partner's slot c: the partner has just evaluated exactly that
-        // rotation from its side (as ITS slot-c rotation); its parameters are mine mirrored.
-        const T gam2 = lane_xor<S>(gam1, s);
-        const T ics2 = lane_xor<S>(ics1, s);
-        const T tl2 = -lane_xor<S>(tl1, s);
+        // rotation from its side (as ITS slot-c rotation); its k is mine with the sign flipped.
+        const T kgh2 = lane_xor<S>(kgh, s);
+        const T kg22 = lane_xor<S>(kg2, s);
+        const T ru2 = lane_xor<S>(ru1, s);
+        const T Dpn = lane_xor<S>(D[c], s);  // partner's slot c, already rescaled
 #pragma unroll
-        for (int r = 0; r < MR; ++r) rv[r] = lane_xor_row<S>(x[c][r], s, r);  // partner's slot c, rotated
-#if SQFA_FAST_GIVENS
-        {
-          // x' = x/cs - tl y_new:  d' = d/cs,  x^' = x^ - (tl d_y,new / d') y^_new
-          const T cs2 = lane_xor<S>(cs1, s);
-          const T dpn = lane_xor<S>(d[c], s);
-          d[cp] *= ics2;
-          id[cp] *= cs2;
-          const T b = -(tl2 * dpn * id[cp]);
+        for (int r = 0; r < MR; ++r) rv[r] = lane_xor_row<S, SWZ>(x[c][r], s, r);  // partner's slot c, rotated
+        const T b = kgh2 * Dpn;
 #pragma unroll
-          for (int r = 0; r < MR; ++r) x[cp][r] = R::fma_(b, rv[r], x[cp][r]);
-        }
-#else
-#pragma unroll
-        for (int r = 0; r < MR; ++r) x[cp][r] = ics2 * x[cp][r] - tl2 * rv[r];
-#endif
-        nrm[cp] -= tl2 * gam2;
+        for (int r = 0; r < MR; ++r) x[cp][r] = R::fma_(b, rv[r], x[cp][r]);
+        D[cp] *= ru2;
+        nrm[cp] += kg22;
       }
     }
   }
 }
 
 template <typename T, int MR, int G, int CPL, int S>
-__device__ __forceinline__ void cross_rounds_static(T (&x)[CPL][MR], T (&nrm)[CPL], T (&d)[CPL], T (&id)[CPL], T tol2,
-                                                    bool& big) {
+__device__ __forceinline__ void cross_rounds_static(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], T tol2, bool& big) {
   if constexpr (S < G) {
-    cross_round<T, MR, CPL, S>(x, nrm, d, id, S, tol2, big);
-    cross_rounds_static<T, MR, G, CPL, S + 1>(x, nrm, d, id, tol2, big);
+    cross_round<T, MR, CPL, S, swizzled_rows_of_8<T, G>()>(x, nrm, D, S, tol2, big);
+    cross_rounds_static<T, MR, G, CPL, S + 1>(x, nrm, D, tol2, big);
   }
 }
 
@@ -566,9 +545,9 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
     }
 
     // ---- 2. one-sided Jacobi ---------------------------------------------------------
-    T nrm[CPL], d[CPL], id[CPL];  // true squared norms; column scales x_true = d x (see cross_round)
+    T nrm[CPL], D[CPL];  // true squared norms; squared column scales, x_true = sqrt(D) x (see rot_scaled)
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) d[c] = id[c] = T(1);
+    for (int c = 0; c < CPL; ++c) D[c] = T(1);
     int sweeps = 0;
     bool more = true;
     while (more && sweeps < Cfg::MAX_SWEEPS) {
@@ -577,69 +556,49 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
         T a = T(0);
 #pragma unroll
         for (int r = 0; r < MR; ++r) a = R::fma_(x[c][r], x[c][r], a);
-        nrm[c] = a * d[c] * d[c];
+        nrm[c] = a * D[c];
       }
       bool big = false;
-#if SQFA_FAST_GIVENS
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) id[c] = R::rcp(d[c]);
-#endif
       // pairs inside my own lane
 #pragma unroll
       for (int c1 = 0; c1 < CPL; ++c1) {
 #pragma unroll
         for (int c2 = c1 + 1; c2 < CPL; ++c2) {
-          T gam = T(0);
+          T gh = T(0);
 #pragma unroll
-          for (int r = 0; r < MR; ++r) gam = R::fma_(x[c1][r], x[c2][r], gam);
-#if SQFA_FAST_GIVENS
-          gam *= d[c1] * d[c2];
-#endif
-          T cs, ics, sn, tl;
-          rot_params(nrm[c1], nrm[c2], gam, tol2, T(1), cs, ics, sn, tl, big);
-#if SQFA_FAST_GIVENS
-          {
-            const T a1 = -(tl * d[c2] * id[c1]), a2 = tl * d[c1] * id[c2];
-#pragma unroll
-            for (int r = 0; r < MR; ++r) {
-              const T xp = x[c1][r];
-              x[c1][r] = R::fma_(a1, x[c2][r], xp);
-              x[c2][r] = R::fma_(a2, xp, x[c2][r]);
-            }
-            d[c1] *= cs;
-            d[c2] *= cs;
-            id[c1] *= ics;
-            id[c2] *= ics;
-          }
-#else
+          for (int r = 0; r < MR; ++r) gh = R::fma_(x[c1][r], x[c2][r], gh);
+          T u, ru, k, g2;
+          rot_scaled(nrm[c1], nrm[c2], gh, D[c1], D[c2], tol2, T(1), u, ru, k, g2, big);
+          const T kgh = k * gh, kg2 = k * g2;
+          const T a1 = -(kgh * D[c2]), a2 = kgh * D[c1];
 #pragma unroll
           for (int r = 0; r < MR; ++r) {
-            const T xp = x[c1][r], xq = x[c2][r];
-            x[c1][r] = cs * xp - sn * xq;
-            x[c2][r] = sn * xp + cs * xq;
+            const T xp = x[c1][r];
+            x[c1][r] = R::fma_(a1, x[c2][r], xp);
+            x[c2][r] = R::fma_(a2, xp, x[c2][r]);
           }
-#endif
-          nrm[c1] -= tl * gam;
-          nrm[c2] += tl * gam;
+          D[c1] *= u;
+          D[c2] *= u;
+          nrm[c1] -= kg2;
+          nrm[c2] += kg2;
         }
       }
       // pairs across the lanes of my group
       if constexpr (G > 1 && G <= Cfg::STATIC_G) {
-        cross_rounds_static<T, MR, G, CPL, 1>(x, nrm, d, id, tol2, big);
+        cross_rounds_static<T, MR, G, CPL, 1>(x, nrm, D, tol2, big);
       } else if constexpr (G > Cfg::STATIC_G) {
 #pragma unroll 1
-        for (int s = 1; s < G; ++s) cross_round<T, MR, CPL, 0>(x, nrm, d, id, s, tol2, big);
+        for (int s = 1; s < G; ++s) cross_round<T, MR, CPL, 0, 0>(x, nrm, D, s, tol2, big);
       }
       more = __any(big);
       ++sweeps;
     }
-#if SQFA_FAST_GIVENS
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
+      const T dc = R::sqrt_(D[c]);
 #pragma unroll
-      for (int r = 0; r < MR; ++r) x[c][r] *= d[c];  // back to the true columns
+      for (int r = 0; r < MR; ++r) x[c][r] *= dc;  // back to the true columns
     }
-#endif
     lane = opaque_lane();
     g = lane % G;
     i = i0 + lane / G;
