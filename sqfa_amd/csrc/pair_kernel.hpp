@@ -82,6 +82,10 @@ template <> struct Real<float> {
 #define SQFA_EARLY2_F32 1.0e-7f
 #endif
   static constexpr float kEarly2 = SQFA_EARLY2_F32;  // a sweep in which every cos^2 between columns stays below this is the last one
+#ifndef SQFA_RENORM_LOG2
+#define SQFA_RENORM_LOG2 24
+#endif
+  static constexpr float kScaleHi = (float)(1ull << SQFA_RENORM_LOG2), kScaleLo = 1.0f / kScaleHi;  // see the sweep loop
   static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
   static __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
   static __device__ __forceinline__ float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
@@ -94,6 +98,7 @@ template <> struct Real<float> {
 template <> struct Real<double> {
   static constexpr double kEps = 2.220446049250313e-16;
   static constexpr double kEarly2 = 1.0e-15;
+  static constexpr double kScaleHi = (double)(1ull << SQFA_RENORM_LOG2), kScaleLo = 1.0 / kScaleHi;
   // v_rcp_f64 seed + one third-order step: 1/x = y (1 + e + e^2 + O(e^3)), e = 1 - x y
   static __device__ __forceinline__ double rcp(double x) {
     const double y = __builtin_amdgcn_rcp(x);
@@ -551,6 +556,24 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
     int sweeps = 0;
     bool more = true;
     while (more && sweeps < Cfg::MAX_SWEEPS) {
+      // D shrinks by cos^2 >= 1/2 per rotation: harmless for the handful of large rotations of
+      // a converging run, but a slow pathological pencil could walk it (and 1/x^) out of the
+      // float32 range over many sweeps.  Fold the scales back into the columns whenever one
+      // leaves [2^-SQFA_RENORM_LOG2, 2^SQFA_RENORM_LOG2] (wave-uniform, practically never).
+      {
+        bool far = false;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) far = far || !(D[c] > R::kScaleLo && D[c] < R::kScaleHi);
+        if (__any(far)) {
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            const T dc = R::sqrt_(D[c]);
+#pragma unroll
+            for (int r = 0; r < MR; ++r) x[c][r] *= dc;
+            D[c] = T(1);
+          }
+        }
+      }
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
         T a = T(0);
