@@ -64,8 +64,9 @@ def hip_pair_backend(A, B, *, scale, eps, sqrt_mode, weights, uniform_weight, sh
     with torch.cuda.device(dev):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         # out_loss / out_gradA: caller-provided views (e.g. into a fused all-reduce buffer)
-        loss = (out_loss if out_loss is not None else torch.zeros((), dtype=A.dtype, device=dev)) if want_loss else None
-        nonfinite = torch.zeros(2, dtype=torch.int32, device=dev)
+        # (loss and the two validity counters are always written by the finalize kernel: no memset)
+        loss = (out_loss if out_loss is not None else torch.empty((), dtype=A.dtype, device=dev)) if want_loss else None
+        nonfinite = torch.empty(2, dtype=torch.int32, device=dev)
         gradA = (out_gradA if out_gradA is not None else torch.empty_like(A)) if want_grad else None
         gradB = torch.empty_like(B) if (want_grad and B is not None) else None
         if want_dist:

@@ -30,9 +30,9 @@ class PairShard:
 
     def reduce_fused(self, buf, flags, shape):
         """Same as `reduce` for a buffer [loss, -, -, grad...] the kernel has already filled."""
-        buf[1:3] = flags.to(buf.dtype)
+        buf[1:3].copy_(flags)  # int32 -> real in the copy itself; small counts are exact in float32
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-        return buf[0], buf[1:3].round().to(torch.int32), buf[3:].view(shape)
+        return buf[0], buf[1:3].to(torch.int32), buf[3:].view(shape)
 
     def reduce(self, loss, flags, grad):
         """Sum (loss, flags, grad) over the ranks with a single all-reduce."""
