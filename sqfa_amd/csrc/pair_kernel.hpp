@@ -66,6 +66,28 @@ template <typename T> __device__ __forceinline__ T param_uniform_weight(const Pa
   if constexpr (sizeof(T) == 4) return p.uniform_weight_f; else return p.uniform_weight;
 }
 
+// ---------------------------------------------------------------------------------------
+// Which tiles exist.  The launch grid is COMPACT: workgroup w of shard r is the w-th tile, in
+// row-major order, among the tiles (bi, bj) that (a) hold at least one pair of the job (self
+// mode: some i > j) and (b) belong to the shard, (bi + bj) % shard_count == shard_index.
+// Launching the full nbi x nbj rectangle and returning early from foreign tiles would be
+// simpler, but workgroups are dealt to the 8 XCDs round-robin by linear id and the stripe
+// pattern (bi + bj) % N is periodic in exactly that id: with N = 2, 4, 8 shards the tiles of a
+// shard all landed on 4, 2, 2 of the 8 XCDs and a shard ran no faster than the whole job.
+__host__ __device__ inline int tiles_in_row(int bi, int nbj, int TI, int TJ, int self_mode) {
+  if (!self_mode) return nbj;
+  const int q = bi * TI + TI - 2;  // tiles with j0 <= i0 + TI - 2 hold a pair i > j
+  if (q < 0) return 0;
+  const int len = q / TJ + 1;
+  return len < nbj ? len : nbj;
+}
+// tiles of block-row bi owned by the shard: bj = first, first + N, ... (count returned)
+__host__ __device__ inline int shard_tiles_in_row(int bi, int len, int shard_index, int shard_count, int* first) {
+  const int o = ((shard_index - bi) % shard_count + shard_count) % shard_count;
+  *first = o;
+  return len > o ? (len - 1 - o) / shard_count + 1 : 0;
+}
+
 __host__ __device__ constexpr int pow2ceil(int v) {
   int p = 1;
   while (p < v) p <<= 1;
@@ -471,10 +493,23 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
   __shared__ T s_red[WAVES];
   __shared__ int s_redi[2 * WAVES];
 
-  const int bi = blockIdx.y, bj = blockIdx.x;
+  // my tile: the blockIdx.x-th tile of this shard (compact grid, see tiles_in_row); scalar search
+  int bi = 0, bj = 0;
+  {
+    int w = blockIdx.x;
+    for (; bi < p.nbi; ++bi) {
+      int first;
+      const int cnt = shard_tiles_in_row(bi, tiles_in_row(bi, p.nbj, TI, TJ, p.self_mode), p.shard_index,
+                                         p.shard_count, &first);
+      if (w < cnt) {
+        bj = first + w * p.shard_count;
+        break;
+      }
+      w -= cnt;
+    }
+    if (bi >= p.nbi) return;  // cannot happen for a grid sized by launch_pair_tiles
+  }
   const int i0 = bi * TI, j0 = bj * TJ;
-  if ((bi + bj) % p.shard_count != p.shard_index) return;
-  if (p.self_mode && (i0 + TI - 1 <= j0)) return;  // no pair with i > j in this tile
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave id in an SGPR
@@ -759,7 +794,14 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
 // host-side launcher, instantiated once per configuration in its own translation unit
 template <typename Cfg>
 hipError_t launch_pair_tiles(const PairParams& p, hipStream_t stream) {
-  dim3 grid(p.nbj, p.nbi, 1);
+  long n_tiles = 0;
+  for (int bi = 0; bi < p.nbi; ++bi) {
+    int first;
+    n_tiles += shard_tiles_in_row(bi, tiles_in_row(bi, p.nbj, Cfg::TI, Cfg::TJ, p.self_mode), p.shard_index,
+                                  p.shard_count, &first);
+  }
+  if (n_tiles == 0) return hipSuccess;  // this shard owns no tile (more shards than tiles)
+  dim3 grid((unsigned)n_tiles, 1, 1);
   using T = typename Cfg::type;
   hipLaunchKernelGGL((pair_tile_kernel<Cfg>), grid, dim3(Cfg::THREADS), 0, stream, p, static_cast<const T*>(p.LT),
                      static_cast<const T*>(p.Linv), static_cast<const T*>(p.W));
