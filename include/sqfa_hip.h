@@ -50,11 +50,13 @@ int sqfa_hip_max_dim(void);            /* largest matrix size m handled natively
 const char *sqfa_hip_last_error(void); /* text of the last HIP error seen by this library (host thread local) */
 
 /*
- * Tile geometry used for a given problem, so that callers can shard work
- * (multi-GPU) and size buffers:  tiles form an n_tiles_i x n_tiles_j grid over
- * (A classes) x (B classes); tile (bi,bj) is processed by the call iff
- * (bi + bj) % shard_count == shard_index (and, in self mode, it contains a pair i>j).
- * Returns SQFA_OK or an error code.
+ * Tile geometry used for a given problem (informational): tiles form an
+ * n_tiles_i x n_tiles_j grid over (A classes) x (B classes); tile (bi,bj) is
+ * processed by a call iff (bi + bj) % shard_count == shard_index (and, in self mode,
+ * it contains a pair i>j).  tile_j / n_tiles_j describe the WIDEST tiling; a call
+ * whose shard would not fill the GPU halves the tile width (possibly repeatedly), which
+ * changes which pairs a shard evaluates but never the union over the shards of one
+ * shard_count.  Returns SQFA_OK or an error code.
  */
 int sqfa_airm_tiling(int nA, int nB, int m, int dtype,
                      int *tile_i, int *tile_j, int *n_tiles_i, int *n_tiles_j, int *padded_m);

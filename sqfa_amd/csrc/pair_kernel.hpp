@@ -52,6 +52,7 @@ struct PairParams {
   int self_mode, sqrt_mode, want_grad;
   int shard_index, shard_count;
   int nbi, nbj;
+  int tj;  // B classes per tile in this launch (<= the configuration's TJ, a multiple of its wave count)
   double scale, eps, uniform_weight;
   float scale_f, eps_f, uniform_weight_f;  // the same three, pre-rounded for the float32 kernels (stay in SGPRs)
 };
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
     const typename Cfg::type* __restrict__ LinvAll, const typename Cfg::type* __restrict__ Wt) {
   using T = typename Cfg::type;
   using R = Real<T>;
-  constexpr int MR = Cfg::MR, G = Cfg::G, CPL = Cfg::CPL, TJ = Cfg::TJ, TI = Cfg::TI;
+  constexpr int MR = Cfg::MR, G = Cfg::G, CPL = Cfg::CPL, TI = Cfg::TI;
   constexpr int WAVES = Cfg::WAVES, TRI = Cfg::TRI, TRIP = Cfg::TRIP, NT = Cfg::THREADS;
 
   __shared__ T s_ga[WAVES * TI * TRIP];  // per-wave private A-side accumulators (lower triangles)
@@ -493,13 +494,14 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
   __shared__ T s_red[WAVES];
   __shared__ int s_redi[2 * WAVES];
 
+  const int tj = p.tj;  // run-time tile width (the host narrows tiles when a launch would not fill the chip)
   // my tile: the blockIdx.x-th tile of this shard (compact grid, see tiles_in_row); scalar search
   int bi = 0, bj = 0;
   {
     int w = blockIdx.x;
     for (; bi < p.nbi; ++bi) {
       int first;
-      const int cnt = shard_tiles_in_row(bi, tiles_in_row(bi, p.nbj, TI, TJ, p.self_mode), p.shard_index,
+      const int cnt = shard_tiles_in_row(bi, tiles_in_row(bi, p.nbj, TI, tj, p.self_mode), p.shard_index,
                                          p.shard_count, &first);
       if (w < cnt) {
         bj = first + w * p.shard_count;
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
     }
     if (bi >= p.nbi) return;  // cannot happen for a grid sized by launch_pair_tiles
   }
-  const int i0 = bi * TI, j0 = bj * TJ;
+  const int i0 = bi * TI, j0 = bj * tj;
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave id in an SGPR
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
     return t & 63;
   };
 
-  for (int jj = wave; jj < TJ; jj += WAVES) {
+  for (int jj = wave; jj < tj; jj += WAVES) {
     const int j = j0 + jj;  // wave-uniform
     int lane = opaque_lane();
     int g = lane % G;
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
     bool valid = (i < p.nA) && (j < p.nB) && (!p.self_mode || i > j);
     if (!__any(valid)) {
       if (p.want_grad) {  // nothing to add for this B class, but the slab entry must be defined
-        T* gbz = static_cast<T*>(p.slab_grad) + ((size_t)tile * (TI + TJ) + TI + jj) * TRI;
+        T* gbz = static_cast<T*>(p.slab_grad) + ((size_t)tile * (TI + tj) + TI + jj) * TRI;
         for (int k = lane; k < TRI; k += 64) gbz[k] = T(0);
       }
       continue;
@@ -752,7 +754,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
         const OuterProduct<T, MR, CPL> prodA{x, coefA};
         constexpr int LG = ilog2(G);
         tree_reduce_blocks<LG, 0, (TRI + G - 1) / G, TRI, T>(prodA, lo, [&](int idx, T v) { ga[idx] += v; });
-        T* gb = static_cast<T*>(p.slab_grad) + ((size_t)tile * (TI + TJ) + TI + jj) * TRI;
+        T* gb = static_cast<T*>(p.slab_grad) + ((size_t)tile * (TI + tj) + TI + jj) * TRI;
         const OuterProduct<T, MR, CPL> prodB{x, coefB};
         tree_reduce_blocks<6, 0, (TRI + 63) / 64, TRI, T>(prodB, lo, [&](int idx, T v) { gb[idx] = v; });
       }
@@ -780,7 +782,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
     p.slab_flag[2 * tile + 1] = ni;
   }
   if (p.want_grad) {
-    T* slab = static_cast<T*>(p.slab_grad) + (size_t)tile * (TI + TJ) * TRI;
+    T* slab = static_cast<T*>(p.slab_grad) + (size_t)tile * (TI + tj) * TRI;
     for (int k = tid_end; k < TI * TRI; k += NT) {
       const int pi = k / TRI, idx = k % TRI;
       T acc = T(0);
@@ -797,7 +799,7 @@ hipError_t launch_pair_tiles(const PairParams& p, hipStream_t stream) {
   long n_tiles = 0;
   for (int bi = 0; bi < p.nbi; ++bi) {
     int first;
-    n_tiles += shard_tiles_in_row(bi, tiles_in_row(bi, p.nbj, Cfg::TI, Cfg::TJ, p.self_mode), p.shard_index,
+    n_tiles += shard_tiles_in_row(bi, tiles_in_row(bi, p.nbj, Cfg::TI, p.tj, p.self_mode), p.shard_index,
                                   p.shard_count, &first);
   }
   if (n_tiles == 0) return hipSuccess;  // this shard owns no tile (more shards than tiles)

@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <utility>
 #include <vector>
 
@@ -19,15 +20,15 @@ SQFA_CONFIGS_F32(SQFA_DECL_F32)
 SQFA_CONFIGS_F64(SQFA_DECL_F64)
 
 struct Geometry {
-  int MR, G, CPL, TJ, TI;
+  int MR, G, CPL, TJ, TI, WV;  // TJ: widest tile (B classes); a launch may use TJ/2, TJ/4 ... >= WV
   hipError_t (*launch)(const PairParams&, hipStream_t);
 };
 
 static bool find_geometry(int m, int dtype, Geometry* out) {
 #define SQFA_ROW_F32(T, MR_, G_, CPL_, TJ_, WV_) \
-  if (dtype == SQFA_F32 && m <= MR_) { *out = Geometry{MR_, G_, CPL_, TJ_, 64 / G_, launch_pair_f32_##MR_}; return true; }
+  if (dtype == SQFA_F32 && m <= MR_) { *out = Geometry{MR_, G_, CPL_, TJ_, 64 / G_, WV_, launch_pair_f32_##MR_}; return true; }
 #define SQFA_ROW_F64(T, MR_, G_, CPL_, TJ_, WV_) \
-  if (dtype == SQFA_F64 && m <= MR_) { *out = Geometry{MR_, G_, CPL_, TJ_, 64 / G_, launch_pair_f64_##MR_}; return true; }
+  if (dtype == SQFA_F64 && m <= MR_) { *out = Geometry{MR_, G_, CPL_, TJ_, 64 / G_, WV_, launch_pair_f64_##MR_}; return true; }
   SQFA_CONFIGS_F32(SQFA_ROW_F32)
   SQFA_CONFIGS_F64(SQFA_ROW_F64)
   return false;
@@ -62,18 +63,50 @@ struct WorkspaceLayout {
   size_t off_lt, off_linv, off_slab, off_loss, off_flag, total;
 };
 
-static WorkspaceLayout layout(int nA, int nBeff, const Geometry& g, size_t esz, int nbi, int nbj) {
+// The workspace is sized for the narrowest tiles a launch may choose (most tiles, largest slab).
+static WorkspaceLayout layout(int nA, int nBeff, const Geometry& g, size_t esz) {
   WorkspaceLayout w;
   const size_t mat = (size_t)g.MR * g.MR * esz;
   const size_t tri = (size_t)g.MR * (g.MR + 1) / 2;
+  const size_t nbi = (nA + g.TI - 1) / g.TI;
+  size_t slab = 0, tiles = 0;
+  for (int tj = g.TJ; tj >= g.WV && tj >= 1; tj /= 2) {
+    const size_t nbj = (nBeff + tj - 1) / tj;
+    slab = std::max(slab, nbi * nbj * (size_t)(g.TI + tj) * tri * esz);
+    tiles = std::max(tiles, nbi * nbj);
+    if (tj % 2) break;
+  }
   size_t o = 0;
   w.off_lt = o;   o = align_up(o + (size_t)nA * mat);
   w.off_linv = o; o = align_up(o + (size_t)nBeff * mat);
-  w.off_slab = o; o = align_up(o + (size_t)nbi * nbj * (g.TI + g.TJ) * tri * esz);
-  w.off_loss = o; o = align_up(o + (size_t)nbi * nbj * esz);
-  w.off_flag = o; o = align_up(o + (size_t)nbi * nbj * 2 * sizeof(int));
+  w.off_slab = o; o = align_up(o + slab);
+  w.off_loss = o; o = align_up(o + tiles * esz);
+  w.off_flag = o; o = align_up(o + tiles * 2 * sizeof(int));
   w.total = o;
   return w;
+}
+
+// Tiles of this shard for tile width tj (same enumeration as the kernel's compact grid).
+static long shard_tiles(int nA, int nBeff, const Geometry& g, int tj, int self_mode, int shard_index, int shard_count) {
+  const int nbi = (nA + g.TI - 1) / g.TI, nbj = (nBeff + tj - 1) / tj;
+  long n = 0;
+  for (int bi = 0; bi < nbi; ++bi) {
+    int first;
+    n += shard_tiles_in_row(bi, tiles_in_row(bi, nbj, g.TI, tj, self_mode), shard_index, shard_count, &first);
+  }
+  return n;
+}
+
+// Workgroups the chip holds at once (4 per CU for the 256-thread configurations); a launch with
+// fewer tiles than this runs for one tile's latency however few they are, so tiles are narrowed.
+static int resident_workgroups() {
+  static int cached = 0;
+  if (cached == 0) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    cached = 4 * (cus > 0 ? cus : 256);
+  }
+  return cached;
 }
 
 // ---- K0: per-class Cholesky factor and its inverse (always evaluated in double) ----------
@@ -184,17 +217,26 @@ __global__ __launch_bounds__(512) void finalize_kernel(const PairParams p, int T
     // NG partial sums are combined in group order: short dependent chains, bitwise reproducible.
     int NG = 512 / TRI;
     NG = NG < 1 ? 1 : (NG > 8 ? 8 : NG);
-    const int n_a = a_side ? p.nbj : 0;                       // tiles (bi, *) holding this class as A
-    const int n_b = (!a_side || p.self_mode) ? p.nbi : 0;     // tiles (*, bj) holding it as B
     const int bi_a = c / TI, pi = c % TI, bj_b = c / TJ, pj = c % TJ;
+    // Only the tiles this shard owns are visited (same enumeration as the pair kernel's grid):
+    //   as A class: tiles (bi_a, first_a + k N), k < n_a   (row bi_a; self mode: up to the diagonal)
+    //   as B class: tiles (first_b + k N, bj_b), k < n_b   (column bj_b; self mode: checked per tile)
+    const int N = p.shard_count;
+    int first_a = 0, n_a = 0, first_b = 0, n_b = 0;
+    if (a_side) n_a = shard_tiles_in_row(bi_a, tiles_in_row(bi_a, p.nbj, TI, TJ, p.self_mode), p.shard_index, N, &first_a);
+    if (!a_side || p.self_mode) {
+      first_b = ((p.shard_index - bj_b) % N + N) % N;
+      n_b = p.nbi > first_b ? (p.nbi - 1 - first_b) / N + 1 : 0;
+    }
     for (int e = tid; e < NG * TRI; e += 512) {
       const int grp = e / TRI, idx = e % TRI;
       T acc = T(0);
       for (int q = grp; q < n_a + n_b; q += NG) {
         if (q < n_a) {
-          if (tile_processed(p, bi_a, q, TI, TJ)) acc += slab[(size_t)(bi_a * p.nbj + q) * tile_stride + (size_t)pi * TRI + idx];
+          const int bj = first_a + q * N;
+          acc += slab[(size_t)(bi_a * p.nbj + bj) * tile_stride + (size_t)pi * TRI + idx];
         } else {
-          const int bi = q - n_a;
+          const int bi = first_b + (q - n_a) * N;
           if (tile_processed(p, bi, bj_b, TI, TJ)) acc += slab[(size_t)(bi * p.nbj + bj_b) * tile_stride + (size_t)(TI + pj) * TRI + idx];
         }
       }
@@ -346,7 +388,7 @@ size_t sqfa_airm_workspace_bytes(int nA, int nB, int m, int dtype) {
   Geometry g;
   find_geometry(m, dtype, &g);
   const int nBeff = nB == 0 ? nA : nB;
-  return layout(nA, nBeff, g, dtype == SQFA_F32 ? 4 : 8, nbi, nbj).total;
+  return layout(nA, nBeff, g, dtype == SQFA_F32 ? 4 : 8).total;
 }
 
 int sqfa_airm_pairwise(const void* A, int nA, const void* B, int nB, int m, int dtype, double scale,
@@ -366,8 +408,15 @@ int sqfa_airm_pairwise(const void* A, int nA, const void* B, int nB, int m, int 
   if (!find_geometry(m, dtype, &g)) return fail(SQFA_ERR_UNSUPPORTED_M, "matrix size not supported", hipSuccess);
   const size_t esz = dtype == SQFA_F32 ? 4 : 8;
   const int nBeff = self_mode ? nA : nB;
-  const int nbi = (nA + g.TI - 1) / g.TI, nbj = (nBeff + g.TJ - 1) / g.TJ;
-  const WorkspaceLayout w = layout(nA, nBeff, g, esz, nbi, nbj);
+  // tile width: halve while a shard's launch would leave workgroup slots empty.  Decided from
+  // the TOTAL tile count and shard_count only, so that every shard of a job picks the same
+  // tiling (tile ownership (bi + bj) % shard_count is defined on that tiling).
+  int tj = g.TJ;
+  while (tj % 2 == 0 && tj / 2 >= g.WV &&
+         shard_tiles(nA, nBeff, g, tj, self_mode ? 1 : 0, 0, 1) / shard_count < resident_workgroups())
+    tj /= 2;
+  const int nbi = (nA + g.TI - 1) / g.TI, nbj = (nBeff + tj - 1) / tj;
+  const WorkspaceLayout w = layout(nA, nBeff, g, esz);
   if (workspace_bytes < w.total) return fail(SQFA_ERR_WORKSPACE, "workspace too small", hipSuccess);
   char* ws = static_cast<char*>(workspace);
 
@@ -392,6 +441,7 @@ int sqfa_airm_pairwise(const void* A, int nA, const void* B, int nB, int m, int 
   p.shard_count = shard_count;
   p.nbi = nbi;
   p.nbj = nbj;
+  p.tj = tj;
   p.scale = scale;
   p.eps = eps;
   p.uniform_weight = uniform_weight;
@@ -446,11 +496,11 @@ int sqfa_airm_pairwise(const void* A, int nA, const void* B, int nB, int m, int 
   // K2: slab reduction
   const int n_cls = nA + (self_mode ? 0 : nB);
   if (dtype == SQFA_F32) {
-    hipLaunchKernelGGL(finalize_kernel<float>, dim3(n_cls + 1), dim3(512), 0, stream, p, g.TI, g.TJ, g.MR,
+    hipLaunchKernelGGL(finalize_kernel<float>, dim3(n_cls + 1), dim3(512), 0, stream, p, g.TI, tj, g.MR,
                        static_cast<float*>(gradA_out), static_cast<float*>(gradB_out),
                        static_cast<float*>(loss_out), nonfinite_out);
   } else {
-    hipLaunchKernelGGL(finalize_kernel<double>, dim3(n_cls + 1), dim3(512), 0, stream, p, g.TI, g.TJ, g.MR,
+    hipLaunchKernelGGL(finalize_kernel<double>, dim3(n_cls + 1), dim3(512), 0, stream, p, g.TI, tj, g.MR,
                        static_cast<double*>(gradA_out), static_cast<double*>(gradB_out),
                        static_cast<double*>(loss_out), nonfinite_out);
   }
