@@ -169,6 +169,41 @@ def test_tile_shards_sum_to_the_whole(world):
     assert rel_err(acc_g.cpu(), full_g.cpu()) < 1e-12
 
 
+@pytest.mark.parametrize("world", [2, 5, 8])
+@pytest.mark.parametrize("cross", [False, True])
+def test_tile_shards_with_narrowed_tiles(world, cross):
+    """At this size the library keeps the wide tiles for the whole job and for 2 shards but
+    narrows them for 5 and 8 (a shard would not fill the GPU): every shard of one shard_count
+    must use the same tiling, so the shards still sum to the whole -- self and cross mode."""
+    from sqfa_amd import _native, distances
+    rng = np.random.default_rng(7)
+    C, m = 600, 16
+    X = rng.standard_normal((C, 2 * m, m))
+    S = torch.tensor(np.einsum("cnm,cnk->cmk", X, X) / (2 * m) + 0.05 * np.eye(m), dtype=torch.float64, device=DEV)
+    A, B = (S[:420], S[380:]) if cross else (S, None)
+
+    def run(shard):
+        out = _native.hip_pair_backend(A, B, scale=1.0, eps=distances.EPSILON, sqrt_mode=True, weights=None,
+                                       uniform_weight=-1e-5, shard=shard, want_loss=True, want_grad=True,
+                                       want_dist=False, want_eig=False)
+        return out["loss"].item(), out["gradA"], out["gradB"], out["nonfinite"].tolist()
+
+    full = run((0, 1))
+    assert full[3] == [0, 0]
+    acc_l, acc_a, acc_b = 0.0, torch.zeros_like(full[1]), None if B is None else torch.zeros_like(full[2])
+    for rank in range(world):
+        l, ga, gb, fl = run((rank, world))
+        assert fl == [0, 0]
+        acc_l += l
+        acc_a += ga
+        if B is not None:
+            acc_b += gb
+    assert abs(acc_l - full[0]) < 1e-11 * abs(full[0])
+    assert rel_err(acc_a.cpu(), full[1].cpu()) < 1e-11
+    if B is not None:
+        assert rel_err(acc_b.cpu(), full[2].cpu()) < 1e-11
+
+
 @pytest.mark.parametrize("C,m,dtype", [(300, 16, torch.float32), (200, 17, torch.float32), (120, 32, torch.float32),
                                        (90, 33, torch.float32), (150, 8, torch.float32), (100, 16, torch.float64),
                                        (40, 40, torch.float32), (30, 48, torch.float64), (24, 64, torch.float32),
