@@ -475,7 +475,11 @@ struct PairCfg {
   static constexpr int STATIC_G = SQFA_STATIC_G;
   // register budget: waves per SIMD the kernel is compiled for (256-thread blocks)
   static constexpr int XREGS = CPL * MR * (int)(sizeof(T) / 4);
-  static constexpr int MIN_WAVES = sizeof(T) == 8 ? (XREGS <= 140 ? 2 : 1) : (XREGS <= 72 ? 4 : (XREGS <= 100 ? 3 : (XREGS <= 170 ? 2 : 1)));
+#ifndef SQFA_F64_SMALL_WAVES
+#define SQFA_F64_SMALL_WAVES 3  // 168 VGPRs: measured 8 % faster than 2 waves at m=16 (LDS allows 3 workgroups per CU)
+#endif
+  static constexpr int MIN_WAVES = sizeof(T) == 8 ? (XREGS <= 64 ? SQFA_F64_SMALL_WAVES : (XREGS <= 140 ? 2 : 1))
+                                                  : (XREGS <= 72 ? 4 : (XREGS <= 100 ? 3 : (XREGS <= 170 ? 2 : 1)));
   static_assert(G * CPL >= MR, "not enough column slots");
   static_assert(TJ % WAVES == 0, "TJ must be a multiple of the wave count");
 };
