@@ -1,6 +1,8 @@
 """Randomised shape sweep of the C-ABI entry point against the float64 closed-form oracle:
 self and cross mode, ragged class counts around the tile edges of every geometry, uniform and
 per-pair weights, sqrt and squared distances, float32 and float64, 1..3 shards."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -20,7 +22,7 @@ def spd(rng, n, m):
 CASES = []
 _rng = np.random.default_rng(2025)
 for m in (1, 2, 3, 4, 5, 7, 8, 9, 13, 16, 17, 20, 31, 32, 33, 41, 48, 57, 64):
-    for _ in range(2):
+    for _ in range(int(os.environ.get("SQFA_FUZZ_ROUNDS", "2"))):  # soak runs: SQFA_FUZZ_ROUNDS=30
         self_mode = bool(_rng.integers(0, 2))
         nA = int(_rng.integers(2, 40 if m <= 17 else 14))
         nB = 0 if self_mode else int(_rng.integers(1, 30 if m <= 17 else 10))
