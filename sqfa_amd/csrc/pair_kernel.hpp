@@ -479,7 +479,7 @@ struct PairCfg {
 #define SQFA_F64_SMALL_WAVES 3  // 168 VGPRs: measured 8 % faster than 2 waves at m=16 (LDS allows 3 workgroups per CU)
 #endif
   static constexpr int MIN_WAVES = sizeof(T) == 8 ? (XREGS <= 64 ? SQFA_F64_SMALL_WAVES : (XREGS <= 140 ? 2 : 1))
-                                                  : (XREGS <= 72 ? 4 : (XREGS <= 100 ? 3 : (XREGS <= 170 ? 2 : 1)));
+                                                  : (XREGS <= 64 ? 4 : (XREGS <= 100 ? 3 : (XREGS <= 170 ? 2 : 1)));
   static_assert(G * CPL >= MR, "not enough column slots");
   static_assert(TJ % WAVES == 0, "TJ must be a multiple of the wave count");
 };
