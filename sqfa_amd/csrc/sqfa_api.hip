@@ -63,30 +63,7 @@ struct WorkspaceLayout {
   size_t off_lt, off_linv, off_slab, off_loss, off_flag, total;
 };
 
-// The workspace is sized for the narrowest tiles a launch may choose (most tiles, largest slab).
-static WorkspaceLayout layout(int nA, int nBeff, const Geometry& g, size_t esz) {
-  WorkspaceLayout w;
-  const size_t mat = (size_t)g.MR * g.MR * esz;
-  const size_t tri = (size_t)g.MR * (g.MR + 1) / 2;
-  const size_t nbi = (nA + g.TI - 1) / g.TI;
-  size_t slab = 0, tiles = 0;
-  for (int tj = g.TJ; tj >= g.WV && tj >= 1; tj /= 2) {
-    const size_t nbj = (nBeff + tj - 1) / tj;
-    slab = std::max(slab, nbi * nbj * (size_t)(g.TI + tj) * tri * esz);
-    tiles = std::max(tiles, nbi * nbj);
-    if (tj % 2) break;
-  }
-  size_t o = 0;
-  w.off_lt = o;   o = align_up(o + (size_t)nA * mat);
-  w.off_linv = o; o = align_up(o + (size_t)nBeff * mat);
-  w.off_slab = o; o = align_up(o + slab);
-  w.off_loss = o; o = align_up(o + tiles * esz);
-  w.off_flag = o; o = align_up(o + tiles * 2 * sizeof(int));
-  w.total = o;
-  return w;
-}
-
-// Tiles of this shard for tile width tj (same enumeration as the kernel's compact grid).
+// Tiles of a shard for tile width tj (same enumeration as the kernel's compact grid).
 static long shard_tiles(int nA, int nBeff, const Geometry& g, int tj, int self_mode, int shard_index, int shard_count) {
   const int nbi = (nA + g.TI - 1) / g.TI, nbj = (nBeff + tj - 1) / tj;
   long n = 0;
@@ -107,6 +84,38 @@ static int resident_workgroups() {
     cached = 4 * (cus > 0 ? cus : 256);
   }
   return cached;
+}
+
+// Tile widths a launch may use: the configuration's TJ, and its halvings (down to the wave
+// count) as long as the job then has at most 16 x the resident workgroups in tiles -- narrowing
+// only ever helps launches that do not fill the chip, and the bound keeps the slab small.
+static bool width_allowed(int nA, int nBeff, const Geometry& g, int tj, int self_mode) {
+  if (tj == g.TJ) return true;
+  if (tj < g.WV || tj < 1 || g.TJ % tj != 0) return false;
+  return shard_tiles(nA, nBeff, g, tj, self_mode, 0, 1) <= 16L * resident_workgroups();
+}
+
+// The workspace is sized for the narrowest tiles a launch may choose (most tiles, largest slab).
+static WorkspaceLayout layout(int nA, int nBeff, const Geometry& g, size_t esz, int self_mode) {
+  WorkspaceLayout w;
+  const size_t mat = (size_t)g.MR * g.MR * esz;
+  const size_t tri = (size_t)g.MR * (g.MR + 1) / 2;
+  const size_t nbi = (nA + g.TI - 1) / g.TI;
+  size_t slab = 0, tiles = 0;
+  for (int tj = g.TJ; tj >= 1 && width_allowed(nA, nBeff, g, tj, self_mode); tj /= 2) {
+    const size_t nbj = (nBeff + tj - 1) / tj;
+    slab = std::max(slab, nbi * nbj * (size_t)(g.TI + tj) * tri * esz);
+    tiles = std::max(tiles, nbi * nbj);
+    if (tj % 2) break;
+  }
+  size_t o = 0;
+  w.off_lt = o;   o = align_up(o + (size_t)nA * mat);
+  w.off_linv = o; o = align_up(o + (size_t)nBeff * mat);
+  w.off_slab = o; o = align_up(o + slab);
+  w.off_loss = o; o = align_up(o + tiles * esz);
+  w.off_flag = o; o = align_up(o + tiles * 2 * sizeof(int));
+  w.total = o;
+  return w;
 }
 
 // ---- K0: per-class Cholesky factor and its inverse (always evaluated in double) ----------
@@ -388,7 +397,7 @@ size_t sqfa_airm_workspace_bytes(int nA, int nB, int m, int dtype) {
   Geometry g;
   find_geometry(m, dtype, &g);
   const int nBeff = nB == 0 ? nA : nB;
-  return layout(nA, nBeff, g, dtype == SQFA_F32 ? 4 : 8).total;
+  return layout(nA, nBeff, g, dtype == SQFA_F32 ? 4 : 8, nB == 0 ? 1 : 0).total;
 }
 
 int sqfa_airm_pairwise(const void* A, int nA, const void* B, int nB, int m, int dtype, double scale,
@@ -412,11 +421,11 @@ int sqfa_airm_pairwise(const void* A, int nA, const void* B, int nB, int m, int 
   // the TOTAL tile count and shard_count only, so that every shard of a job picks the same
   // tiling (tile ownership (bi + bj) % shard_count is defined on that tiling).
   int tj = g.TJ;
-  while (tj % 2 == 0 && tj / 2 >= g.WV &&
+  while (tj % 2 == 0 && width_allowed(nA, nBeff, g, tj / 2, self_mode ? 1 : 0) &&
          shard_tiles(nA, nBeff, g, tj, self_mode ? 1 : 0, 0, 1) / shard_count < resident_workgroups())
     tj /= 2;
   const int nbi = (nA + g.TI - 1) / g.TI, nbj = (nBeff + tj - 1) / tj;
-  const WorkspaceLayout w = layout(nA, nBeff, g, esz);
+  const WorkspaceLayout w = layout(nA, nBeff, g, esz, self_mode ? 1 : 0);
   if (workspace_bytes < w.total) return fail(SQFA_ERR_WORKSPACE, "workspace too small", hipSuccess);
   char* ws = static_cast<char*>(workspace);
 
