@@ -160,7 +160,8 @@ def cpu_baseline(S_cpu, scale, C_full, seconds_budget=25.0):
     except (OSError, ValueError):
         pass
     torch.set_num_threads(threads)
-    C_s = min(C_full, 300)
+    # sample size: ~10 s of host work for the default workload (3 evaluations of ~3 s at m <= 17)
+    C_s = min(C_full, 500 if S_cpu.shape[-1] <= 17 else 300)
     sample = S_cpu[:C_s].clone()
     t0 = time.perf_counter()
     reference_path.pairwise_loss_and_grad(sample[:60], scale=scale)  # warm-up (MKL init)
