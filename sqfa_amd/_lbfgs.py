@@ -133,11 +133,24 @@ class CompactLBFGS(torch.optim.LBFGS):
 
             ls_func_evals = 0
             self._add_grad(t, d)
+            step_max = None
             if n_iter != max_iter:
                 with torch.enable_grad():
-                    loss = float(closure().detach())
+                    loss_t = closure().detach()
                 flat_grad = self._gather_flat_grad()
-                opt_cond = flat_grad.abs().max() <= tolerance_grad
+                if flat_grad.is_cuda:
+                    # one read-back for everything the stopping rules need (instead of three
+                    # synchronisations): loss, max |g|, max |t d|
+                    parts = [flat_grad.abs().max(), d.mul(t).abs().max()]
+                    if loss_t.is_cuda:
+                        parts.append(loss_t.to(flat_grad.dtype).reshape(()))
+                    vals = torch.stack(parts).tolist()
+                    g_max, step_max = vals[0], vals[1]
+                    loss = vals[2] if loss_t.is_cuda else float(loss_t)
+                    opt_cond = g_max <= tolerance_grad
+                else:
+                    loss = float(loss_t)
+                    opt_cond = flat_grad.abs().max() <= tolerance_grad
                 ls_func_evals = 1
 
             current_evals += ls_func_evals
@@ -149,7 +162,7 @@ class CompactLBFGS(torch.optim.LBFGS):
                 break
             if opt_cond:
                 break
-            if d.mul(t).abs().max() <= tolerance_change:
+            if (step_max if step_max is not None else d.mul(t).abs().max()) <= tolerance_change:
                 break
             if abs(loss - prev_loss) < tolerance_change:
                 break

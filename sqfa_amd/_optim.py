@@ -174,8 +174,9 @@ def fitting_loop(model, data_statistics, max_epochs=200, lr=0.1, atol=1e-6, show
                 p.grad = grad  # the static gradient tensors the graph writes
             if use_host:
                 return unpack_to_host(packed)
-            raise_on_flags(packed[1:3].round().to(torch.int32))
-            return packed[0].clone()  # the static buffer is overwritten by the next replay
+            head = packed[:3].cpu()  # loss and flags in one read-back; the gradient stays on the device
+            raise_on_flags(head[1:3].round().to(torch.int32))
+            return head[0]
         graph["calls"] += 1
         for p in device_params:
             p.grad = None
