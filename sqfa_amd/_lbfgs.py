@@ -64,6 +64,10 @@ class _History:
 class CompactLBFGS(torch.optim.LBFGS):
     """Drop-in for torch.optim.LBFGS (same constructor)."""
 
+    # None: gather the per-iteration decision scalars in one device-to-host copy when the
+    # parameters live on a GPU; True/False force the choice (tests run the fused path on the CPU)
+    fuse_readback = None
+
     @torch.no_grad()
     def step(self, closure):
         group = self.param_groups[0]
@@ -99,6 +103,7 @@ class CompactLBFGS(torch.optim.LBFGS):
         prev_loss = state.get("prev_loss")
 
         n_iter = 0
+        ahead = None
         while n_iter < max_iter:
             n_iter += 1
             state["n_iter"] += 1
@@ -108,9 +113,13 @@ class CompactLBFGS(torch.optim.LBFGS):
                 hist = _History(history_size, flat_grad)
                 H_diag = 1
             else:
-                y = flat_grad.sub(prev_flat_grad)
-                s = d.mul(t)
-                ys = y.dot(s)
+                if ahead is not None:
+                    y, s, ys = ahead  # formed (and ys read back) together with the stopping-rule scalars
+                    ahead = None
+                else:
+                    y = flat_grad.sub(prev_flat_grad)
+                    s = d.mul(t)
+                    ys = y.dot(s)
                 if ys > 1e-10:
                     hist.push(y, s)
                     H_diag = ys / y.dot(y)
@@ -138,15 +147,18 @@ class CompactLBFGS(torch.optim.LBFGS):
                 with torch.enable_grad():
                     loss_t = closure().detach()
                 flat_grad = self._gather_flat_grad()
-                if flat_grad.is_cuda:
+                if flat_grad.is_cuda if self.fuse_readback is None else self.fuse_readback:
                     # one read-back for everything the stopping rules need (instead of three
                     # synchronisations): loss, max |g|, max |t d|
-                    parts = [flat_grad.abs().max(), d.mul(t).abs().max()]
-                    if loss_t.is_cuda:
+                    # ... and s.y of the NEXT iteration, whose sign decides the history update
+                    y_next, s_next = flat_grad.sub(prev_flat_grad), d.mul(t)
+                    parts = [flat_grad.abs().max(), s_next.abs().max(), y_next.dot(s_next)]
+                    if loss_t.device == flat_grad.device:
                         parts.append(loss_t.to(flat_grad.dtype).reshape(()))
                     vals = torch.stack(parts).tolist()
                     g_max, step_max = vals[0], vals[1]
-                    loss = vals[2] if loss_t.is_cuda else float(loss_t)
+                    ahead = (y_next, s_next, vals[2])
+                    loss = vals[3] if loss_t.device == flat_grad.device else float(loss_t)
                     opt_cond = g_max <= tolerance_grad
                 else:
                     loss = float(loss_t)

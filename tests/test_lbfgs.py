@@ -12,7 +12,11 @@ def rosenbrock_like(x):
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 2e-3)])
 @pytest.mark.parametrize("history_size", [100, 5])
-def test_matches_torch_lbfgs(dtype, tol, history_size):
+@pytest.mark.parametrize("fuse_readback", [False, True])
+def test_matches_torch_lbfgs(dtype, tol, history_size, fuse_readback, monkeypatch):
+    # fuse_readback=True: the path GPU parameters take (decision scalars gathered in one copy,
+    # s.y of the next iteration formed ahead), forced here on CPU tensors
+    monkeypatch.setattr(CompactLBFGS, "fuse_readback", fuse_readback)
     torch.manual_seed(0)
     x0 = torch.randn(40, dtype=dtype) * 0.5
     runs = []
