@@ -42,7 +42,7 @@ struct PairParams {
   const void* LT;     // [nA][MR*MR]  LT[c][k] = L_A[k][c]  (columns of L contiguous), identity padded
   const void* Linv;   // [nB][MR*MR]  row-major inverse Cholesky factor of B, identity padded
   const void* W;      // optional (nA,nB) pair weights, or nullptr
-  void* slab_grad;    // [nbi*nbj][TI+TJ][TRI]
+  void* slab_grad;    // [nbi*nbj][TI+tj][TRI]  lower triangles: TI A-side rows, then tj B-side rows per tile
   void* slab_loss;    // [nbi*nbj]
   int* slab_flag;     // [nbi*nbj][2]  {NaN count, inf count}
   void* dist_out;     // (nA,nB) or nullptr
