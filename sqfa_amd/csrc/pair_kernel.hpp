@@ -297,7 +297,7 @@ __device__ __forceinline__ void rot_scaled(T no, T nr, T gh, T Dx, T Dy, T tol2,
 // rotated afterwards against the partner's ALREADY ROTATED slot c, with the algebraically
 // equivalent form  x' = x/cos - tan y_new, i.e.  x^' = x^ - (k gh Dy_new) y^_new,  Dx' = Dx/u,
 // so only one MR-long temporary is live at a time.
-template <typename T, int MR, int CPL, int S, int SWZ>
+template <typename T, int MR, int CPL, int S, int SWZ, bool LONE_LAST>
 __device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], int s, T tol2, bool& big) {
   using R = Real<T>;
   constexpr int TP2 = pow2ceil(CPL);
@@ -309,6 +309,9 @@ __device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
     for (int c = 0; c < CPL; ++c) {
       const int cp = c ^ t;
       if (cp < c || cp >= CPL) continue;  // resolved at compile time after unrolling
+      // LONE_LAST: the last slot holds a real column in ONE lane of the group only (MR = G(CPL-1)+1,
+      // e.g. 17 = 4*4+1), so no two lanes ever have a last-slot pair to rotate
+      if (LONE_LAST && c == CPL - 1 && cp == CPL - 1) continue;
       T rv[MR];
 #pragma unroll
       for (int r = 0; r < MR; ++r) rv[r] = lane_xor_row<S, SWZ>(x[cp][r], s, r);  // partner's slot cp
@@ -349,7 +352,7 @@ __device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
 template <typename T, int MR, int G, int CPL, int S>
 __device__ __forceinline__ void cross_rounds_static(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], T tol2, bool& big) {
   if constexpr (S < G) {
-    cross_round<T, MR, CPL, S, swizzled_rows_of_8<T, G>()>(x, nrm, D, S, tol2, big);
+    cross_round<T, MR, CPL, S, swizzled_rows_of_8<T, G>(), (MR == G * (CPL - 1) + 1)>(x, nrm, D, S, tol2, big);
     cross_rounds_static<T, MR, G, CPL, S + 1>(x, nrm, D, tol2, big);
   }
 }
@@ -569,7 +572,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
     T x[CPL][MR];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-      const int col = g * CPL + c;
+      const int col = c * G + g;  // columns dealt round-robin: slot c of lane g is column c*G + g
       const T* src = lt + (size_t)(col < MR ? col : 0) * MR;
       const bool real_col = col < MR;
 #pragma unroll
@@ -652,7 +655,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
         cross_rounds_static<T, MR, G, CPL, 1>(x, nrm, D, tol2, big);
       } else if constexpr (G > Cfg::STATIC_G) {
 #pragma unroll 1
-        for (int s = 1; s < G; ++s) cross_round<T, MR, CPL, 0, 0>(x, nrm, D, s, tol2, big);
+        for (int s = 1; s < G; ++s) cross_round<T, MR, CPL, 0, 0, (MR == G * (CPL - 1) + 1)>(x, nrm, D, s, tol2, big);
       }
       more = __any(big);
       ++sweeps;
@@ -677,7 +680,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
     T part = T(0);
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-      const int col = g * CPL + c;
+      const int col = c * G + g;  // columns dealt round-robin: slot c of lane g is column c*G + g
       T a = T(0);
 #pragma unroll
       for (int r = 0; r < MR; ++r) a = R::fma_(x[c][r], x[c][r], a);
@@ -713,7 +716,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
       T* E = static_cast<T*>(p.eig_out);
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
-        const int col = g * CPL + c;
+        const int col = c * G + g;  // columns dealt round-robin: slot c of lane g is column c*G + g
         if (col < p.m) {
           E[((size_t)io * p.nB + j) * p.m + col] = lam[c];
           if (p.self_mode) E[((size_t)j * p.nB + io) * p.m + col] = T(1) / lam[c];
