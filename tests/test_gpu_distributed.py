@@ -74,3 +74,58 @@ def test_two_ranks_on_one_gpu_match_single_process():
     assert np.array_equal(F0, F1)
     assert np.abs(fl0 - G4["syn_sqfa_K2_e3_loss"]).max() < 1e-6
     assert np.linalg.norm(F0 - G4["syn_sqfa_K2_e3_filters"]) < 1e-7 * np.linalg.norm(F0)
+
+
+def _rccl_worker(port, q):
+    """World of ONE rank on backend "nccl" (= RCCL): the collective calls of the multi-GPU path
+    (fused-buffer all-reduce, all-gather of class slices, gradient all-reduce, barrier) run
+    through the real library, with the same tensors, as far as a one-GPU box allows."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        import model_cases as mc
+        from sqfa_amd import _native, distances
+        from sqfa_amd.parallel import ClassShard, PairShard
+        G1 = load_golden("g1_airm_self.npz")
+        shard = PairShard()
+        S = torch.tensor(G1["C37_m16_S"], dtype=torch.float32, device=dev)
+        # the fused buffer exactly as PairwiseLoss.forward / bench.py build it for world > 1
+        fused = torch.empty(S.numel() + 3, dtype=S.dtype, device=dev)
+        out = _native.hip_pair_backend(S, None, scale=1.0, eps=distances.EPSILON, sqrt_mode=True, weights=None,
+                                       uniform_weight=-1.0 / 666, shard=(0, 1), want_loss=True, want_grad=True,
+                                       want_dist=False, want_eig=False, out_loss=fused[0],
+                                       out_gradA=fused[3:].view(S.shape))
+        loss, flags, grad = shard.reduce_fused(fused, out["nonfinite"], S.shape)
+        dist.barrier()
+        stats = mc.fit_stats("syn", torch.float64, dev)
+        model = mc.make_model("sqfa", 50, 2, 1e-3, "sphere", torch.float64, dev)
+        model.pair_shard = shard
+        model.class_shard = ClassShard(20)
+        model.fit_pca(data_statistics=stats)
+        fl, _ = model.fit(data_statistics=stats, max_epochs=3, show_progress=False, return_loss=True)
+        q.put((loss.item(), flags.tolist(), grad.cpu().numpy(), fl.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rccl_backend_single_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(29800 + os.getpid() % 2000, q))
+    p.start()
+    loss, flags, grad, fl = q.get(timeout=500)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    G1 = load_golden("g1_airm_self.npz")
+    G4 = load_golden("g4_fit.npz")
+    ref_l = float(G1["C37_m16_loss_f64"])
+    assert flags == [0, 0]
+    assert abs(loss - ref_l) < 1e-5 * abs(ref_l)
+    assert np.linalg.norm(grad - G1["C37_m16_grad_f64"]) < 5e-5 * np.linalg.norm(G1["C37_m16_grad_f64"])
+    assert np.abs(fl - G4["syn_sqfa_K2_e3_loss"]).max() < 1e-6
