@@ -199,7 +199,15 @@ def test_linalg_helpers_and_shapes():
     W = linalg.spd_inv_sqrt(spd)
     assert rel_err(W @ spd @ W.transpose(1, 2), g5["spd_inv_sqrt_whitened"]) < 1e-10
     gv, ge = linalg.generalized_eigenvectors(spd[:3], spd[1:4])
-    assert rel_err(gv.abs(), g5["gen_eigvec_abs"]) < 1e-8 and rel_err(ge, g5["gen_eigval"]) < 1e-10
+    assert rel_err(ge, g5["gen_eigval"]) < 1e-10
+    for i in range(3):
+        for j in range(3):
+            A, B, V, lam = spd[i], spd[1 + j], gv[i, j], ge[i, j]
+            # defining properties for every pair: A v = lambda B v, unit-norm columns
+            assert rel_err(A @ V, (B @ V) * lam) < 1e-9
+            assert torch.allclose(torch.linalg.norm(V, dim=0), torch.ones(3, dtype=V.dtype), atol=1e-12)
+            if i != 1 + j:  # (A_i == B_j gives a fully degenerate pencil: any basis is an answer)
+                assert rel_err(V.abs(), g5["gen_eigvec_abs"][i, j]) < 1e-8
     for nA, nB, nd_d, nd_l in g5["squeeze_shapes"]:
         A, B = spd[:nA], spd[:nB]
         assert distances.affine_invariant_sq(A, B).dim() == nd_d
