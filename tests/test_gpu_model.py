@@ -217,3 +217,19 @@ def test_graph_captured_closure_reports_nonfinite(monkeypatch):
     with pytest.raises(ValueError, match="NaN"):
         model.fit(data_statistics=S, max_epochs=3, show_progress=False)
     assert calls[0] >= 2  # warm-up closure + the capture
+
+
+def test_device_side_compact_lbfgs_matches_torch_lbfgs(monkeypatch):
+    """Parameters too large for the host-side optimizer state (> 8192 elements): CompactLBFGS with
+    its fused read-backs on the device against torch.optim.LBFGS itself, same closures."""
+    import sqfa_amd._optim as opt
+    stats = {k: v.to(DEV) for k, v in mc.c2_statistics(C=12, D=2304).items()}
+    runs = {}
+    for compact in (False, True):
+        monkeypatch.setattr(opt, "COMPACT_LBFGS", compact)
+        model = mc.make_model("smsqfa", 2304, 4, 0.01, "sphere", torch.float64, DEV)   # 9216 parameters
+        model.fit_pca(data_statistics=stats)
+        loss, _ = model.fit(data_statistics=stats, max_epochs=4, show_progress=False, return_loss=True)
+        runs[compact] = (loss.numpy(), model.filters.detach().cpu().numpy())
+    assert np.abs(runs[True][0] - runs[False][0]).max() < 1e-9
+    assert rel_err(runs[True][1], runs[False][1]) < 1e-7
