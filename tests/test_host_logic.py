@@ -245,3 +245,10 @@ def test_custom_distance_fun_uses_generic_closure():
     assert model._fused_closure_loss(cov) is None
     loss, _ = model.fit(data_statistics=cov, max_epochs=2, show_progress=False, return_loss=True)
     assert torch.isfinite(loss).all()
+
+
+def test_usable_cpus_is_positive_and_bounded():
+    import os
+    from sqfa_amd.statistics import usable_cpus
+    n = usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
