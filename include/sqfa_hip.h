@@ -118,6 +118,21 @@ int sqfa_airm_pairwise(const void *A, int nA, const void *B, int nB, int m, int 
 int sqfa_project_scatters(const void *F, int K, int D, const void *Psi, int C, int dtype, void *T_out,
                           void *stream);
 
+/*
+ * The two small products around it, each reading T (C,D,K) once:
+ *   sqfa_feature_scatters           S_c = F T_c            -> S_out (C,K,K)   (the projected scatters;
+ *                                   noise / embedding are added by the caller)
+ *   sqfa_feature_scatters_backward  P_g = sum over the classes c = g, g + n_groups, ... of
+ *                                   (G_c + G_c^T) T_c^T  -> partial_out (n_groups,K,D); G (C,K,K) is
+ *                                   the gradient wrt S; dL/dF = sum_g P_g (fixed order: reproducible)
+ * They replace the einsum of conjugate_matrix (src/sqfa/linalg.py:41) and its autograd backward.
+ * float32 or float64, K <= 64; forward needs D % 4 == 0, backward K % 4 == 0
+ * (SQFA_ERR_UNSUPPORTED_M otherwise: the caller keeps its own expression).
+ */
+int sqfa_feature_scatters(const void *F, int K, int D, const void *T, int C, int dtype, void *S_out, void *stream);
+int sqfa_feature_scatters_backward(const void *G, const void *T, int C, int D, int K, int dtype, int n_groups,
+                                   void *partial_out, void *stream);
+
 /* Introspection (benchmarks / development; not needed by a reference-side binding).
  *
  * sqfa_airm_set_sweep_counter: register a device buffer of two uint64 {sum of Jacobi sweeps,

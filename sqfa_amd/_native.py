@@ -186,10 +186,20 @@ def native_projection_supported(scatters, filters):
 class ProjectScatters(torch.autograd.Function):
     """S_c = F Psi_c F^T for symmetric Psi_c, reading Psi (C,D,D) from HBM once.
 
-    forward : T = Psi F^T through sqfa_project_scatters (HIP, MFMA f32), S = F T (tiny bmm)
-    backward: dL/dF = sum_c (G_c + G_c^T) T_c^T  -- needs T (C,D,K) only, not Psi.
+    forward : T = Psi F^T through sqfa_project_scatters (streaming MFMA kernel), S = F T through
+              sqfa_feature_scatters
+    backward: dL/dF = sum_c (G_c + G_c^T) T_c^T through sqfa_feature_scatters_backward -- needs
+              T (C,D,K) only, not Psi.
     Replaces conjugate_matrix (reference src/sqfa/linalg.py:19-45) in transform_scatters
     (src/sqfa/model.py:172-188), whose autograd reads Psi a second time in the backward."""
+
+    # class groups of the backward kernel: 64 keeps ~3000 waves in flight at D = 784 (one per
+    # 16-column block and group; the kernel is latency-bound) and the (groups, K, D) partial sums at 3 MB
+    BACKWARD_GROUPS = 64
+    # S = F T and dL/dF go through the HIP kernels from this many classes on (measured, closure at
+    # C=1000, D=784, K=16: 1.61 -> 1.56 ms); below, torch's batched GEMMs are as fast (both are
+    # launch/latency-bound there).  A huge value selects the torch expressions everywhere.
+    NATIVE_PRODUCTS_MIN_CLASSES = 256
 
     @staticmethod
     def forward(ctx, filters, scatters):
@@ -198,24 +208,40 @@ class ProjectScatters(torch.autograd.Function):
         Psi = scatters.detach().contiguous()
         K, D = F.shape
         C = Psi.shape[0]
+        code = _dtype_code(Psi)
         with torch.cuda.device(Psi.device):
             T = torch.empty((C, D, K), dtype=Psi.dtype, device=Psi.device)
-            stream = torch.cuda.current_stream(Psi.device).cuda_stream
-            status = lib.sqfa_project_scatters(_ptr(F), K, D, _ptr(Psi), C, _dtype_code(Psi), _ptr(T),
-                                               ctypes.c_void_p(stream))
-        _lib.check(status, "sqfa_project_scatters")
+            S = torch.empty((C, K, K), dtype=Psi.dtype, device=Psi.device)
+            stream = ctypes.c_void_p(torch.cuda.current_stream(Psi.device).cuda_stream)
+            _lib.check(lib.sqfa_project_scatters(_ptr(F), K, D, _ptr(Psi), C, code, _ptr(T), stream),
+                       "sqfa_project_scatters")
+            if C >= ProjectScatters.NATIVE_PRODUCTS_MIN_CLASSES:
+                _lib.check(lib.sqfa_feature_scatters(_ptr(F), K, D, _ptr(T), C, code, _ptr(S), stream),
+                           "sqfa_feature_scatters")
+            else:
+                S = torch.matmul(F.unsqueeze(0), T)
         ctx.save_for_backward(T)
-        return torch.matmul(F.unsqueeze(0), T)
+        return S
 
     @staticmethod
     def backward(ctx, gS):
         (T,) = ctx.saved_tensors
+        C, D, K = T.shape
+        if K % 4 == 0 and C >= ProjectScatters.NATIVE_PRODUCTS_MIN_CLASSES:
+            lib = _lib.load()
+            G = gS.contiguous()
+            groups = min(ProjectScatters.BACKWARD_GROUPS, C)
+            with torch.cuda.device(T.device):
+                partial = torch.empty((groups, K, D), dtype=T.dtype, device=T.device)
+                stream = ctypes.c_void_p(torch.cuda.current_stream(T.device).cuda_stream)
+                _lib.check(lib.sqfa_feature_scatters_backward(_ptr(G), _ptr(T), C, D, K, _dtype_code(T), groups,
+                                                              _ptr(partial), stream), "sqfa_feature_scatters_backward")
+            return partial.sum(dim=0), None
+        # few classes (launch-bound either way) or a filter count that is not a multiple of 4:
+        # per-class (K,K)@(K,D) products, then the sum over classes.  (One flat GEMM (K, C*K)@(C*K, D) is the same arithmetic but hipBLASLt is
+        # erratic for that skinny shape: 8 ms at C=1000, K=16 in isolation.)
         sym = gS + gS.transpose(1, 2)
-        # per-class (K,K)@(K,D) products, then the sum over classes.  (One flat GEMM
-        # (K, C*K)@(C*K, D) is the same arithmetic but hipBLASLt is erratic for that skinny
-        # shape: 8 ms at C=1000, K=16 in isolation.)
-        gF = torch.bmm(sym, T.transpose(1, 2)).sum(dim=0)
-        return gF, None
+        return torch.bmm(sym, T.transpose(1, 2)).sum(dim=0), None
 
 
 def project_scatters(scatters, filters):

@@ -1,0 +1,183 @@
+// feature_kernels.hip -- the two small products around the streaming projection (project_kernel.hip):
+//
+//   forward   S_c = F T_c                         (K x K per class; T_c = Psi_c F^T, (D,K) row-major)
+//   backward  dL/dF = sum_c (G_c + G_c^T) T_c^T   (K x D), as per-class-group partial sums
+//
+// Both read T (C,D,K) exactly once (50 MB at c3) and are HBM/latency-bound; in torch they were a
+// batched GEMM, a batched GEMM writing a (C,K,D) intermediate, an elementwise add and a
+// reduction over classes (~170 us per closure at c3, 10 % of it).  Exact-f32 / f64 MFMA
+// 16x16x4, operand layouts in proj_traits.hpp.  Reference: the einsum of conjugate_matrix
+// (src/sqfa/linalg.py:41) and its autograd backward, as used by transform_scatters
+// (src/sqfa/model.py:172-188).
+#include <hip/hip_runtime.h>
+
+#include "../../include/sqfa_hip.h"
+#include "proj_traits.hpp"
+
+namespace sqfa {
+
+// ---- forward: one workgroup per class; wave (w, part) owns output rows [16 w, 16 w + 16) and every
+// SPLIT-th contraction step (the kernel is latency-bound: T_c comes from HBM, 196 dependent steps
+// in one wave would leave 4 loads in flight); the SPLIT partial tiles are summed through LDS.
+// step s contracts d = 4s .. 4s+3:  A[i][k] = F[16 w + i][4 s + k],  B[k][j] = T_c[4 s + k][16 nb + j]
+// (for K = 16 the 64 lanes of a wave read 256 contiguous bytes of T per step).
+template <typename T, int NB, int SPLIT>
+__global__ __launch_bounds__(64 * NB * SPLIT) void feature_scatters_kernel(const T* __restrict__ F,
+                                                                           const T* __restrict__ Tm,
+                                                                           T* __restrict__ S, int D, int K) {
+  using Tr = ProjTraits<T>;
+  using Acc = typename Tr::Acc;
+  __shared__ T s_part[SPLIT][NB][NB][4][64];
+  const int c = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int w = wave % NB, part = wave / NB;
+  const int r16 = lane & 15, q = lane >> 4;
+  const int row = 16 * w + r16;
+  const T* __restrict__ f = F + (size_t)(row < K ? row : 0) * D + q;
+  const T* __restrict__ t = Tm + (size_t)c * D * K + (size_t)q * K + r16;
+  Acc acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) acc[nb][reg] = T(0);
+  const int steps = D / 4;
+#pragma unroll 8
+  for (int s = part; s < steps; s += SPLIT) {
+    const T a = row < K ? f[4 * s] : T(0);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const T b = (16 * nb + r16 < K) ? t[(size_t)4 * s * K + 16 * nb] : T(0);
+      acc[nb] = Tr::mfma(a, b, acc[nb]);
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) s_part[part][w][nb][reg][lane] = acc[nb][reg];
+  __syncthreads();
+  if (part != 0) return;
+  T* out = S + (size_t)c * K * K;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      T v = T(0);
+#pragma unroll
+      for (int p2 = 0; p2 < SPLIT; ++p2) v += s_part[p2][w][nb][reg][lane];  // fixed order
+      const int a_row = 16 * w + Tr::acc_row(q, reg), b_col = 16 * nb + r16;
+      if (a_row < K && b_col < K) out[(size_t)a_row * K + b_col] = v;
+    }
+  }
+}
+
+// ---- backward: one wave per (16-column block of d, class group) -----------------------------
+// P_g[a][d] = sum_{c in group g} sum_b (G_c[a][b] + G_c[b][a]) T_c[d][b].  Per class and chunk of 16 b's
+// a lane loads 4 consecutive b's of its T row (the 16 rows of the block are 16*K contiguous
+// elements) and of its G row; MFMA step e contracts b = 16 bc + 4 q + e on both operands:
+//   A[i][k] = sym[16 na + i][16 bc + 4 k + e],  B[k][j] = T_c[d0 + j][16 bc + 4 k + e].
+// Classes are visited in a fixed order and the groups are summed in a fixed order by the
+// caller: bitwise reproducible.
+template <typename T, int NB>
+__global__ __launch_bounds__(64) void feature_backward_kernel(const T* __restrict__ G, const T* __restrict__ Tm,
+                                                              T* __restrict__ P, int C, int D, int K, int n_groups) {
+  using Tr = ProjTraits<T>;
+  using Acc = typename Tr::Acc;
+  const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
+  const int d = 16 * blockIdx.x + r16, g = blockIdx.y;
+  const bool d_ok = d < D;
+  Acc acc[NB];
+#pragma unroll
+  for (int na = 0; na < NB; ++na)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) acc[na][reg] = T(0);
+  for (int c = g; c < C; c += n_groups) {
+    const T* __restrict__ tc = Tm + ((size_t)c * D + (d_ok ? d : 0)) * K;
+    const T* __restrict__ gc = G + (size_t)c * K * K;
+    // all loads of the class first (independent), then the MFMAs
+    T tv[NB][4], sv[NB][NB][4];
+#pragma unroll
+    for (int bc = 0; bc < NB; ++bc) {
+      const int b0 = 16 * bc + 4 * q;  // my four contraction indices b0 .. b0+3 (K % 4 == 0)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tv[bc][e] = (d_ok && b0 < K) ? tc[b0 + e] : T(0);
+#pragma unroll
+      for (int na = 0; na < NB; ++na) {
+        const int a = 16 * na + r16;
+        const bool ok = a < K && b0 < K;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          sv[bc][na][e] = ok ? gc[(size_t)a * K + b0 + e] + gc[(size_t)(b0 + e) * K + a] : T(0);
+      }
+    }
+#pragma unroll
+    for (int bc = 0; bc < NB; ++bc)
+#pragma unroll
+      for (int na = 0; na < NB; ++na)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[na] = Tr::mfma(sv[bc][na][e], tv[bc][e], acc[na]);
+  }
+  T* out = P + (size_t)g * K * D;
+#pragma unroll
+  for (int na = 0; na < NB; ++na) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int a = 16 * na + Tr::acc_row(q, reg);
+      if (a < K && d_ok) out[(size_t)a * D + d] = acc[na][reg];
+    }
+  }
+}
+
+template <typename T>
+static void launch_forward(const T* f, const T* t, T* s, int C, int D, int K, hipStream_t stream) {
+  switch ((K + 15) / 16) {
+    case 1: hipLaunchKernelGGL((feature_scatters_kernel<T, 1, 8>), dim3(C), dim3(512), 0, stream, f, t, s, D, K); break;
+    case 2: hipLaunchKernelGGL((feature_scatters_kernel<T, 2, 4>), dim3(C), dim3(512), 0, stream, f, t, s, D, K); break;
+    case 3: hipLaunchKernelGGL((feature_scatters_kernel<T, 3, 2>), dim3(C), dim3(384), 0, stream, f, t, s, D, K); break;
+    default: hipLaunchKernelGGL((feature_scatters_kernel<T, 4, 2>), dim3(C), dim3(512), 0, stream, f, t, s, D, K); break;
+  }
+}
+
+template <typename T>
+static void launch_backward(const T* g, const T* t, T* p, int C, int D, int K, int n_groups, hipStream_t stream) {
+  const dim3 grid((D + 15) / 16, n_groups, 1), block(64);
+  switch ((K + 15) / 16) {
+    case 1: hipLaunchKernelGGL((feature_backward_kernel<T, 1>), grid, block, 0, stream, g, t, p, C, D, K, n_groups); break;
+    case 2: hipLaunchKernelGGL((feature_backward_kernel<T, 2>), grid, block, 0, stream, g, t, p, C, D, K, n_groups); break;
+    case 3: hipLaunchKernelGGL((feature_backward_kernel<T, 3>), grid, block, 0, stream, g, t, p, C, D, K, n_groups); break;
+    default: hipLaunchKernelGGL((feature_backward_kernel<T, 4>), grid, block, 0, stream, g, t, p, C, D, K, n_groups); break;
+  }
+}
+
+static bool shape_ok(int K, int D, int C, int dtype) {
+  return K >= 1 && C >= 1 && D >= 4 && (dtype == SQFA_F32 || dtype == SQFA_F64);
+}
+
+}  // namespace sqfa
+
+extern "C" int sqfa_feature_scatters(const void* F, int K, int D, const void* T, int C, int dtype, void* S_out,
+                                     void* stream_) {
+  using namespace sqfa;
+  if (F == nullptr || T == nullptr || S_out == nullptr || !shape_ok(K, D, C, dtype)) return SQFA_ERR_BAD_ARGUMENT;
+  if ((D % 4) != 0 || K > 64) return SQFA_ERR_UNSUPPORTED_M;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (dtype == SQFA_F32)
+    launch_forward(static_cast<const float*>(F), static_cast<const float*>(T), static_cast<float*>(S_out), C, D, K, stream);
+  else
+    launch_forward(static_cast<const double*>(F), static_cast<const double*>(T), static_cast<double*>(S_out), C, D, K, stream);
+  return hipGetLastError() == hipSuccess ? SQFA_OK : SQFA_ERR_LAUNCH;
+}
+
+extern "C" int sqfa_feature_scatters_backward(const void* G, const void* T, int C, int D, int K, int dtype, int n_groups,
+                                              void* partial_out, void* stream_) {
+  using namespace sqfa;
+  if (G == nullptr || T == nullptr || partial_out == nullptr || !shape_ok(K, D, C, dtype) || n_groups < 1)
+    return SQFA_ERR_BAD_ARGUMENT;
+  if ((K % 4) != 0 || K > 64) return SQFA_ERR_UNSUPPORTED_M;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (dtype == SQFA_F32)
+    launch_backward(static_cast<const float*>(G), static_cast<const float*>(T), static_cast<float*>(partial_out), C, D, K,
+                    n_groups, stream);
+  else
+    launch_backward(static_cast<const double*>(G), static_cast<const double*>(T), static_cast<double*>(partial_out), C, D,
+                    K, n_groups, stream);
+  return hipGetLastError() == hipSuccess ? SQFA_OK : SQFA_ERR_LAUNCH;
+}

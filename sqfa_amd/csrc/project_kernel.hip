@@ -25,32 +25,12 @@
 #include <vector>
 
 #include "../../include/sqfa_hip.h"
+#include "proj_traits.hpp"
 
 bool sqfa_profile_enabled();                                            // sqfa_api.hip
 std::vector<std::pair<hipEvent_t, hipEvent_t>>& sqfa_project_events();  // sqfa_api.hip
 
 namespace sqfa {
-
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-using f64x2 = __attribute__((ext_vector_type(2))) double;
-using f64x4 = __attribute__((ext_vector_type(4))) double;
-
-// per-dtype pieces: the 16-byte load (VW elements), the exact MFMA, and the C/D row map
-template <typename T> struct ProjTraits;
-template <> struct ProjTraits<float> {
-  using Vec = f32x4;
-  using Acc = f32x4;
-  static constexpr int VW = 4;
-  static __device__ __forceinline__ Acc mfma(float a, float b, Acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-  static __device__ __forceinline__ int acc_row(int q, int reg) { return 4 * q + reg; }  // v_mfma_f32_16x16x4_f32
-};
-template <> struct ProjTraits<double> {
-  using Vec = f64x2;
-  using Acc = f64x4;
-  static constexpr int VW = 2;
-  static __device__ __forceinline__ Acc mfma(double a, double b, Acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-  static __device__ __forceinline__ int acc_row(int q, int reg) { return q + 4 * reg; }  // v_mfma_f64_16x16x4_f64
-};
 
 template <typename T, int NB, int KC, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void project_kernel(const T* __restrict__ F, const T* __restrict__ Psi,

@@ -265,12 +265,15 @@ def test_exactly_degenerate_pairs(m, dtype):
     assert torch.allclose(Dt, expect, atol=1e-5)
 
 
+@pytest.mark.parametrize("native_products", [True, False])
 @pytest.mark.parametrize("C,D,K", [(3, 8, 2), (5, 64, 16), (7, 100, 5), (4, 784, 16), (2, 2048, 32), (3, 132, 33),
-                                   (2, 256, 64), (1, 16, 16), (6, 60, 48)])
-def test_streaming_projection_vs_torch(C, D, K):
-    """sqfa_project_scatters + ProjectScatters against the float64 torch expression of
-    conjugate_matrix (values and the gradient with respect to the filters)."""
+                                   (2, 256, 64), (1, 16, 16), (6, 60, 48), (37, 72, 20), (300, 96, 12)])
+def test_streaming_projection_vs_torch(C, D, K, native_products, monkeypatch):
+    """sqfa_project_scatters (+ sqfa_feature_scatters / _backward, or torch's batched GEMMs for the
+    two small products) against the float64 torch expression of conjugate_matrix: values and the
+    gradient with respect to the filters."""
     from sqfa_amd import _native, linalg
+    monkeypatch.setattr(_native.ProjectScatters, "NATIVE_PRODUCTS_MIN_CLASSES", 1 if native_products else 10 ** 9)
     g = torch.Generator().manual_seed(C * 1000 + D + K)
     A = torch.randn(C, D, D // 2 + 1, generator=g, dtype=torch.float64)
     Psi = (A @ A.transpose(1, 2) / A.shape[-1] + 0.05 * torch.eye(D, dtype=torch.float64))
