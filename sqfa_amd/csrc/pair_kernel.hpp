@@ -40,7 +40,7 @@ namespace sqfa {
 
 struct PairParams {
   const void* LT;     // [nA][MR*MR]  LT[c][k] = L_A[k][c]  (columns of L contiguous), identity padded
-  const void* Linv;   // [nB][MR*MR]  row-major inverse Cholesky factor of B, identity padded
+  const void* Linv;   // [nB][MR(MR+1)/2]  inverse Cholesky factor of B, packed lower triangle (row r at r(r+1)/2), identity padded
   const void* W;      // optional (nA,nB) pair weights, or nullptr
   void* slab_grad;    // [nbi*nbj][TI+tj][TRI]  lower triangles: TI A-side rows, then tj B-side rows per tile
   void* slab_loss;    // [nbi*nbj]
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
   constexpr int WAVES = Cfg::WAVES, TRI = Cfg::TRI, TRIP = Cfg::TRIP, NT = Cfg::THREADS;
 
   __shared__ T s_ga[WAVES * TI * TRIP];  // per-wave private A-side accumulators (lower triangles)
-  __shared__ T s_li[WAVES * MR * MR];    // L_j^-1 of the B class each wave is working on
+  __shared__ T s_li[WAVES * TRI];        // L_j^-1 (packed lower triangle) of the B class each wave is working on
   __shared__ T s_red[WAVES];
   __shared__ int s_redi[2 * WAVES];
 
@@ -560,10 +560,10 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
     }
     const T* lt = LT + (size_t)(i < p.nA ? i : p.nA - 1) * (MR * MR);
     const int jc = __builtin_amdgcn_readfirstlane(j < p.nB ? j : p.nB - 1);
-    T* li = s_li + wave * (MR * MR);
+    T* li = s_li + wave * TRI;
     {
-      const T* __restrict__ src = LinvAll + (size_t)jc * (MR * MR);
-      for (int k = lane; k < MR * MR; k += 64) li[k] = src[k];
+      const T* __restrict__ src = LinvAll + (size_t)jc * TRI;
+      for (int k = lane; k < TRI; k += 64) li[k] = src[k];
     }
 
     // ---- 1. X = L_j^-1 L_i, my CPL columns ------------------------------------------
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
       for (int c = 0; c < CPL; ++c) acc[c] = T(0);
 #pragma unroll
       for (int k = 0; k <= r; ++k) {
-        const T l = li[r * MR + k];
+        const T l = li[tri_index(r, k)];
 #pragma unroll
         for (int c = 0; c < CPL; ++c) acc[c] = R::fma_(l, x[c][k], acc[c]);
       }
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
         for (int c = 0; c < CPL; ++c) acc[c] = T(0);
 #pragma unroll
         for (int q = r; q < MR; ++q) {
-          const T l = li[q * MR + r];
+          const T l = li[tri_index(q, r)];
 #pragma unroll
           for (int c = 0; c < CPL; ++c) acc[c] = R::fma_(l, x[c][q], acc[c]);
         }
