@@ -89,6 +89,7 @@ __host__ __device__ inline int shard_tiles_in_row(int bi, int len, int shard_ind
   return len > o ? (len - 1 - o) / shard_count + 1 : 0;
 }
 
+__host__ __device__ constexpr int ilog2(int v);
 __host__ __device__ constexpr int pow2ceil(int v) {
   int p = 1;
   while (p < v) p <<= 1;
@@ -506,15 +507,33 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
   int bi = 0, bj = 0;
   {
     int w = blockIdx.x;
-    for (; bi < p.nbi; ++bi) {
-      int first;
-      const int cnt = shard_tiles_in_row(bi, tiles_in_row(bi, p.nbj, TI, tj, p.self_mode), p.shard_index,
-                                         p.shard_count, &first);
-      if (w < cnt) {
-        bj = first + w * p.shard_count;
-        break;
+    if (p.shard_count == 1) {
+      // single shard: every tile of a row is mine; tile widths are powers of two (no divisions)
+      const int sh = ilog2(tj);
+      for (; bi < p.nbi; ++bi) {
+        const int qq = bi * TI + TI - 2;
+        int len = p.nbj;
+        if (p.self_mode) {
+          const int l2 = qq < 0 ? 0 : (qq >> sh) + 1;
+          len = l2 < len ? l2 : len;
+        }
+        if (w < len) {
+          bj = w;
+          break;
+        }
+        w -= len;
       }
-      w -= cnt;
+    } else {
+      for (; bi < p.nbi; ++bi) {
+        int first;
+        const int cnt = shard_tiles_in_row(bi, tiles_in_row(bi, p.nbj, TI, tj, p.self_mode), p.shard_index,
+                                           p.shard_count, &first);
+        if (w < cnt) {
+          bj = first + w * p.shard_count;
+          break;
+        }
+        w -= cnt;
+      }
     }
     if (bi >= p.nbi) return;  // cannot happen for a grid sized by launch_pair_tiles
   }
