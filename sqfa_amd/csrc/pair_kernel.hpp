@@ -40,7 +40,8 @@ namespace sqfa {
 
 struct PairParams {
   const void* LT;     // [nA][MR*MR]  LT[c][k] = L_A[k][c]  (columns of L contiguous), identity padded
-  const void* Linv;   // [nB][MR(MR+1)/2]  inverse Cholesky factor of B, packed lower triangle (row r at r(r+1)/2), identity padded
+  const void* Linv;   // inverse Cholesky factor of each B class, identity padded: [nB][MR*MR] row-major, or
+                      // [nB][MR(MR+1)/2] packed lower triangle (row r at r(r+1)/2) for MR >= 32 (PairCfg::PACK_LINV)
   const void* W;      // optional (nA,nB) pair weights, or nullptr
   void* slab_grad;    // [nbi*nbj][TI+tj][TRI]  lower triangles: TI A-side rows, then tj B-side rows per tile
   void* slab_loss;    // [nbi*nbj]
@@ -484,6 +485,11 @@ struct PairCfg {
 #endif
   static constexpr int MIN_WAVES = sizeof(T) == 8 ? (XREGS <= 64 ? SQFA_F64_SMALL_WAVES : (XREGS <= 140 ? 2 : 1))
                                                   : (XREGS <= 64 ? 4 : (XREGS <= 100 ? 3 : (XREGS <= 170 ? 2 : 1)));
+  // L_j^-1 staged in LDS as a packed lower triangle (one-wave workgroups, m >= 32: 8 instead of 7
+  // workgroups per CU) or as a full MR x MR block (smaller sizes: no occupancy to gain, and the
+  // regular row pitch keeps the back-transform's LDS reads vectorised and out of the spill range)
+  static constexpr bool PACK_LINV = MR_ >= 32;
+  static constexpr int LINV_ELEMS = PACK_LINV ? MR_ * (MR_ + 1) / 2 : MR_ * MR_;
   static_assert(G * CPL >= MR, "not enough column slots");
   static_assert(TJ % WAVES == 0, "TJ must be a multiple of the wave count");
 };
@@ -498,7 +504,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
   constexpr int WAVES = Cfg::WAVES, TRI = Cfg::TRI, TRIP = Cfg::TRIP, NT = Cfg::THREADS;
 
   __shared__ T s_ga[WAVES * TI * TRIP];  // per-wave private A-side accumulators (lower triangles)
-  __shared__ T s_li[WAVES * TRI];        // L_j^-1 (packed lower triangle) of the B class each wave is working on
+  __shared__ T s_li[WAVES * Cfg::LINV_ELEMS];  // L_j^-1 of the B class each wave is working on (layout: Cfg::PACK_LINV)
   __shared__ T s_red[WAVES];
   __shared__ int s_redi[2 * WAVES];
 
@@ -579,10 +585,12 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
     }
     const T* lt = LT + (size_t)(i < p.nA ? i : p.nA - 1) * (MR * MR);
     const int jc = __builtin_amdgcn_readfirstlane(j < p.nB ? j : p.nB - 1);
-    T* li = s_li + wave * TRI;
+    constexpr int LE = Cfg::LINV_ELEMS;
+    auto li_at = [](int r, int k) constexpr { return Cfg::PACK_LINV ? tri_index(r, k) : r * Cfg::MR + k; };
+    T* li = s_li + wave * LE;
     {
-      const T* __restrict__ src = LinvAll + (size_t)jc * TRI;
-      for (int k = lane; k < TRI; k += 64) li[k] = src[k];
+      const T* __restrict__ src = LinvAll + (size_t)jc * LE;
+      for (int k = lane; k < LE; k += 64) li[k] = src[k];
     }
 
     // ---- 1. X = L_j^-1 L_i, my CPL columns ------------------------------------------
@@ -604,7 +612,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
       for (int c = 0; c < CPL; ++c) acc[c] = T(0);
 #pragma unroll
       for (int k = 0; k <= r; ++k) {
-        const T l = li[tri_index(r, k)];
+        const T l = li[li_at(r, k)];
 #pragma unroll
         for (int c = 0; c < CPL; ++c) acc[c] = R::fma_(l, x[c][k], acc[c]);
       }
@@ -762,7 +770,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
         for (int c = 0; c < CPL; ++c) acc[c] = T(0);
 #pragma unroll
         for (int q = r; q < MR; ++q) {
-          const T l = li[tri_index(q, r)];
+          const T l = li[li_at(q, r)];
 #pragma unroll
           for (int c = 0; c < CPL; ++c) acc[c] = R::fma_(l, x[c][q], acc[c]);
         }

@@ -110,7 +110,7 @@ static WorkspaceLayout layout(int nA, int nBeff, const Geometry& g, size_t esz, 
   }
   size_t o = 0;
   w.off_lt = o;   o = align_up(o + (size_t)nA * mat);
-  w.off_linv = o; o = align_up(o + (size_t)nBeff * tri * esz);
+  w.off_linv = o; o = align_up(o + (size_t)nBeff * mat);  // (packed for MR >= 32: uses about half)
   w.off_slab = o; o = align_up(o + slab);
   w.off_loss = o; o = align_up(o + tiles * esz);
   w.off_flag = o; o = align_up(o + tiles * 2 * sizeof(int));
@@ -120,7 +120,8 @@ static WorkspaceLayout layout(int nA, int nBeff, const Geometry& g, size_t esz, 
 
 // ---- K0: per-class Cholesky factor and its inverse (always evaluated in double) ----------
 // One 256-thread workgroup per class, matrix in LDS.  LT[c][col*MR + k] = L[k][col];
-// Linv[c][r(r+1)/2 + k] = (L^-1)[r][k], k <= r (packed).  Both are padded to MR x MR with an identity block.
+// Linv[c][r*MR + k] = (L^-1)[r][k] (MR < 32) or packed Linv[c][r(r+1)/2 + k], k <= r (MR >= 32).
+// Both are padded to MR x MR with an identity block.
 // A non-SPD input produces NaNs, which surface as non-finite distances (nonfinite_out),
 // never as a fault.
 //   Cholesky: right-looking, all (r,c) entries of the trailing block updated in parallel
@@ -191,9 +192,13 @@ __global__ __launch_bounds__(256) void cholesky_kernel(const T* __restrict__ S, 
       double v = (r < m && k < m) ? (k >= r ? a[k][r] : 0.0) : (r == k ? 1.0 : 0.0);
       LT[base + idx] = (T)v;
     }
-    if (Linv != nullptr && k <= r) {  // packed lower triangle: half the LDS per wave in the pair kernel
-      double v = (r < m && k < m) ? b[r][k] : (r == k ? 1.0 : 0.0);
-      Linv[(size_t)c * (MR * (MR + 1) / 2) + tri_index(r, k)] = (T)v;
+    if (Linv != nullptr) {
+      double v = (r < m && k < m) ? (k <= r ? b[r][k] : 0.0) : (r == k ? 1.0 : 0.0);
+      if (MR >= 32) {  // packed lower triangle (PairCfg::PACK_LINV): less LDS per wave in the pair kernel
+        if (k <= r) Linv[(size_t)c * (MR * (MR + 1) / 2) + tri_index(r, k)] = (T)v;
+      } else {
+        Linv[base + idx] = (T)v;
+      }
     }
   }
 }
