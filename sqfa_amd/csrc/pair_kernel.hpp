@@ -492,6 +492,7 @@ struct PairCfg {
   static constexpr int LINV_ELEMS = PACK_LINV ? MR_ * (MR_ + 1) / 2 : MR_ * MR_;
   static_assert(G * CPL >= MR, "not enough column slots");
   static_assert(TJ % WAVES == 0, "TJ must be a multiple of the wave count");
+  static_assert((TJ & (TJ - 1)) == 0, "TJ must be a power of two (run-time halving, shift-based tile search)");
 };
 
 template <typename Cfg>
