@@ -207,7 +207,9 @@ def test_tile_shards_with_narrowed_tiles(world, cross):
 @pytest.mark.parametrize("C,m,dtype", [(300, 16, torch.float32), (200, 17, torch.float32), (120, 32, torch.float32),
                                        (90, 33, torch.float32), (150, 8, torch.float32), (100, 16, torch.float64),
                                        (40, 40, torch.float32), (30, 48, torch.float64), (24, 64, torch.float32),
-                                       (12, 57, torch.float64), (70, 5, torch.float32), (33, 12, torch.float64)])
+                                       (12, 57, torch.float64), (70, 5, torch.float32), (33, 12, torch.float64),
+                                       (150, 24, torch.float32), (180, 12, torch.float32), (60, 20, torch.float64),
+                                       (90, 9, torch.float32), (50, 23, torch.float64)])
 def test_medium_sizes_vs_closed_form_oracle(C, m, dtype):
     """Sizes the numpy oracle still finishes in seconds; exercises many tiles and ragged edges."""
     rng = np.random.default_rng(C * 100 + m)
