@@ -223,11 +223,12 @@ def test_medium_sizes_vs_closed_form_oracle(C, m, dtype):
     assert rel_err(grad.cpu(), grad_ref) <= (1e-8 if f64 else 5e-5)
 
 
-def test_full_size_properties_c3():
-    """BASELINE config c3 (C=1000, m=16): size-independent properties instead of an oracle run:
-    congruence invariance d(G S G^T) = d(S), inversion invariance, gradient sums."""
+@pytest.mark.parametrize("C,m", [(1000, 16), (1000, 17), (1000, 32), (600, 33)])
+def test_full_size_properties(C, m):
+    """BASELINE configs c3 / c3-SQFA / c4 / c4-SQFA sizes (C=1000, m=16, 17, 32; 33 at C=600):
+    size-independent properties instead of an oracle run: congruence invariance
+    d(G S G^T) = d(S), inversion invariance, gradient sums, float32 against float64."""
     torch.manual_seed(0)
-    C, m = 1000, 16
     X = torch.randn(C, 4 * m, m, dtype=torch.float64)
     S = (X.transpose(1, 2) @ X / (4 * m) + 0.05 * torch.eye(m, dtype=torch.float64)).to(DEV)
     Gm = (torch.randn(m, m, dtype=torch.float64) + 3 * torch.eye(m, dtype=torch.float64)).to(DEV)
