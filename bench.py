@@ -75,7 +75,7 @@ def make_feature_scatters(C, D, K, model, device, dtype=torch.float32, seed=1234
     return S.to(dtype).contiguous(), scale
 
 
-def closure_benchmark(C, D, K, model_name, device, steps, lib):
+def closure_benchmark(C, D, K, model_name, device, steps, lib, with_fit=False):
     """Secondary measurement (metric M2 of SURVEY.md 8d, N=1 only): one full closure = projection
     of the (C,D,D) scatters through the current filters (streaming HIP kernel), fused pairwise
     loss+grad, backward to the raw filter parameter.  Reports closures/s and the HBM roofline of
@@ -124,8 +124,24 @@ def closure_benchmark(C, D, K, model_name, device, steps, lib):
     byts = 4.0 * C * D * D
     gbs = byts / (k_ms * 1e-3) / 1e9
 
-    # tertiary measurement (metric M3): fit() wall-clock to the reference stopping rule from the
-    # fit_pca initialisation, on the same statistics
+    result = {
+        "value": steps / elapsed,
+        "unit": "closures/s",
+        "ms_per_closure": elapsed / steps * 1e3,
+        "what": f"projection F Psi_c F^T of (C={C},D={D},D) scatters + fused pairwise loss+grad + backward to the raw filters ({model_name}, K={K})",
+        "pair_kernel_ms": ms2.value / max(n2.value, 1),
+        "loss": loss.item(),
+        "roofline": {
+            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "traffic": None, "kernel": "project_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": byts,
+        },
+    }
+    if not with_fit:
+        return result
+
+    # tertiary measurement (metric M3, --fit): fit() wall-clock to the reference stopping rule from
+    # the fit_pca initialisation, on the same statistics.  Opt-in, so that the kernel statistics of
+    # the default command only contain launches on the benchmark's own input.
     stats_for_fit = prepared
     evals = [0]
     fused = model._fused_closure_loss
@@ -161,19 +177,8 @@ def closure_benchmark(C, D, K, model_name, device, steps, lib):
         "ms_per_closure": fit_seconds / max(evals[0], 1) * 1e3, "final_loss": float(fit_loss[-1]),
         "what": "model.fit() from the fit_pca initialisation to the reference's stopping rule (|dloss| < 1e-6 for 3 epochs), float32",
     }
-    return {
-        "value": steps / elapsed,
-        "unit": "closures/s",
-        "ms_per_closure": elapsed / steps * 1e3,
-        "what": f"projection F Psi_c F^T of (C={C},D={D},D) scatters + fused pairwise loss+grad + backward to the raw filters ({model_name}, K={K})",
-        "pair_kernel_ms": ms2.value / max(n2.value, 1),
-        "loss": loss.item(),
-        "fit": fit,
-        "roofline": {
-            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-            "traffic": None, "kernel": "project_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": byts,
-        },
-    }
+    result["fit"] = fit
+    return result
 
 
 def pmc_traffic(kernel, workload, dtype):
@@ -235,6 +240,7 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-closure", action="store_true", help="skip the secondary full-closure measurement (N=1)")
+    ap.add_argument("--fit", action="store_true", help="also time model.fit() (metric M3) inside the closure object")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -364,7 +370,7 @@ def main():
         if not args.no_closure and world == 1 and dtype == torch.float32:
             del S, grad
             torch.cuda.empty_cache()
-            result["closure"] = closure_benchmark(C, D, K, model, device, max(10, min(100, args.steps // 2)), lib)
+            result["closure"] = closure_benchmark(C, D, K, model, device, max(10, min(100, args.steps // 2)), lib, with_fit=args.fit)
             result["closure"]["roofline"]["traffic"] = pmc_traffic("project_kernel", args.workload, args.dtype)
             result["closure"]["roofline"]["traffic_unit"] = "bytes per launch (profiles/r1_pmc_c3.json)"
         if not args.no_cpu_baseline and world == 1:
