@@ -122,7 +122,10 @@ template <> struct Real<float> {
 };
 template <> struct Real<double> {
   static constexpr double kEps = 2.220446049250313e-16;
-  static constexpr double kEarly2 = 1.0e-15;
+#ifndef SQFA_EARLY2_F64
+#define SQFA_EARLY2_F64 1.0e-15
+#endif
+  static constexpr double kEarly2 = SQFA_EARLY2_F64;
   static constexpr double kScaleHi = (double)(1ull << SQFA_RENORM_LOG2), kScaleLo = 1.0 / kScaleHi;
   // v_rcp_f64 seed + one third-order step: 1/x = y (1 + e + e^2 + O(e^3)), e = 1 - x y
   static __device__ __forceinline__ double rcp(double x) {
