@@ -6,7 +6,7 @@ resident in HBM, produce the scalar loss -mean_{i>j} d(S_i,S_j) and dloss/dS.
 Workload (default) = BASELINE.json configs[2] "c3": C=1000 classes, n_dim=784, n_filters=16,
 float32, SecondMomentsSQFA (m=16), synthetic Gaussians of SURVEY.md 8(d).
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]          (N > 1: spawns one rank per GPU itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 With N > 1 every rank holds the same S, evaluates the tile shard (bi+bj) % N == rank and the
@@ -231,6 +231,37 @@ def cpu_baseline(S_cpu, scale, C_full, seconds_budget=25.0):
     }
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without torch.distributed.run: start one child process per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, exactly what torch.distributed.run
+    would set), relay rank 0's JSON line, return the worst exit code.  Runs BEFORE anything in this
+    process touches the GPU, and never replaces a process: children are plain subprocesses."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode]
+    for p in procs[1:]:
+        try:
+            codes.append(p.wait(timeout=120))
+        except subprocess.TimeoutExpired:  # rank 0 is gone: a rank still alive is stuck in a collective
+            p.kill()
+            codes.append(p.wait())
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -240,15 +271,23 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-closure", action="store_true", help="skip the secondary full-closure measurement (N=1)")
+    ap.add_argument("--no-c4-pairs", action="store_true", help="skip the second (m=32) pair workload of the scaling curve")
     ap.add_argument("--fit", action="store_true", help="also time model.fit() (metric M3) inside the closure object")
+    ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.launcher_selftest:  # CPU check of the launcher: no GPU, no process group
+        if rank == 0:
+            print(json.dumps({"selftest": True, "world": world, "rank": rank, "local_rank": local_rank,
+                              "master": os.environ.get("MASTER_ADDR"), "port": int(os.environ.get("MASTER_PORT", "0"))}))
+        return
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # rehearsal aid: SQFA_BENCH_REHEARSAL=1 runs all ranks on cuda:0 over gloo (one-GPU box)
     rehearsal = os.environ.get("SQFA_BENCH_REHEARSAL") == "1"
     if rehearsal:
@@ -272,54 +311,76 @@ def main():
 
     C, D, K, model = WORKLOADS[args.workload]
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
-    S, scale = make_feature_scatters(C, D, K, model, device, dtype)
-    m = S.shape[1]
-    P = C * (C - 1) // 2
-    weight = -1.0 / P
     lib = _lib.load()
-
-    def step():
-        # exactly what sqfa_amd._native.PairwiseLoss.forward does inside a closure
-        if world > 1:
-            fused = torch.empty(S.numel() + 3, dtype=S.dtype, device=device)
-            out = _native.hip_pair_backend(S, None, scale=scale, eps=_native.EPSILON, sqrt_mode=True, weights=None,
-                                           uniform_weight=weight, shard=shard.shard, want_loss=True, want_grad=True,
-                                           want_dist=False, want_eig=False, out_loss=fused[0],
-                                           out_gradA=fused[3:].view(S.shape))
-            return shard.reduce_fused(fused, out["nonfinite"], S.shape)
-        out = _native.hip_pair_backend(S, None, scale=scale, eps=_native.EPSILON, sqrt_mode=True, weights=None,
-                                       uniform_weight=weight, shard=shard.shard, want_loss=True, want_grad=True,
-                                       want_dist=False, want_eig=False)
-        return out["loss"], out["nonfinite"], out["gradA"]
+    import ctypes
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        loss, flags, grad = step()
-    fence()
-    lib.sqfa_airm_profile(1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, flags, grad = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    lib.sqfa_airm_profile(0)
-    import ctypes
-    ms_total, launches = ctypes.c_double(0), ctypes.c_int(0)
-    lib.sqfa_airm_profile_read(ctypes.byref(ms_total), ctypes.byref(launches))
-    kernel_ms = ms_total.value / max(launches.value, 1)
+    def time_pair_workload(S, scale, warmup, steps):
+        """W untimed + K timed loss+grad evaluations of the pair workload S; returns
+        (seconds for the K steps [max over ranks], pair kernel ms per launch [max over ranks], last outputs)."""
+        P_ = S.shape[0] * (S.shape[0] - 1) // 2
+        weight = -1.0 / P_
 
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = tmax.item()
-        kmax = torch.tensor([kernel_ms], dtype=torch.float64, device=device)
-        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
-        kernel_ms = kmax.item()
+        def step():
+            # exactly what sqfa_amd._native.PairwiseLoss.forward does inside a closure
+            if world > 1:
+                fused = torch.empty(S.numel() + 3, dtype=S.dtype, device=device)
+                out = _native.hip_pair_backend(S, None, scale=scale, eps=_native.EPSILON, sqrt_mode=True, weights=None,
+                                               uniform_weight=weight, shard=shard.shard, want_loss=True, want_grad=True,
+                                               want_dist=False, want_eig=False, out_loss=fused[0],
+                                               out_gradA=fused[3:].view(S.shape))
+                return shard.reduce_fused(fused, out["nonfinite"], S.shape)
+            out = _native.hip_pair_backend(S, None, scale=scale, eps=_native.EPSILON, sqrt_mode=True, weights=None,
+                                           uniform_weight=weight, shard=shard.shard, want_loss=True, want_grad=True,
+                                           want_dist=False, want_eig=False)
+            return out["loss"], out["nonfinite"], out["gradA"]
+
+        for _ in range(warmup):
+            res = step()
+        fence()
+        lib.sqfa_airm_profile(1)  # HIP events around the pair kernel on its launch stream (asynchronous records)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = step()
+        fence()
+        seconds = time.perf_counter() - t0
+        lib.sqfa_airm_profile(0)
+        ms_total, launches = ctypes.c_double(0), ctypes.c_int(0)
+        lib.sqfa_airm_profile_read(ctypes.byref(ms_total), ctypes.byref(launches))
+        k_ms = ms_total.value / max(launches.value, 1)
+        if world > 1:
+            both = torch.tensor([seconds, k_ms], dtype=torch.float64, device=device)
+            dist.all_reduce(both, op=dist.ReduceOp.MAX)
+            seconds, k_ms = both.tolist()
+        return seconds, k_ms, res
+
+    S, scale = make_feature_scatters(C, D, K, model, device, dtype)
+    m = S.shape[1]
+    P = C * (C - 1) // 2
+    elapsed, kernel_ms, (loss, flags, grad) = time_pair_workload(S, scale, args.warmup, args.steps)
     assert flags.tolist() == [0, 0], f"non-finite distances: {flags.tolist()}"
+
+    # second pair workload for the scaling curve: BASELINE config 4's pair stage (C=1000, m=32), 8x the
+    # work per pair of c3, so that the per-evaluation fixed costs (launches, one all-reduce) stay small
+    # against the kernel also at 8 ranks.  Same sharding, same step; every rank takes part.
+    c4_pairs = None
+    if args.workload != "c4" and not args.no_c4_pairs and dtype == torch.float32:
+        C4, D4, K4, model4 = WORKLOADS["c4"]
+        S4, scale4 = make_feature_scatters(C4, D4, K4, model4, device, dtype)
+        steps4, warm4 = max(5, min(40, args.steps)), max(2, min(10, args.warmup))
+        sec4, kms4, (loss4, flags4, _g4) = time_pair_workload(S4, scale4, warm4, steps4)
+        assert flags4.tolist() == [0, 0]
+        c4_pairs = {
+            "workload": f"c4 pair stage: C={C4} classes, n_filters={K4} (m={S4.shape[1]}), {C4 * (C4 - 1) // 2} unordered pairs per eval",
+            "value": steps4 / sec4, "unit": "evals/s", "n_gpus": world, "steps": steps4, "warmup": warm4,
+            "ms_per_step": sec4 / steps4 * 1e3, "scaling": "strong", "pair_kernel_ms": kms4, "loss": loss4.item(),
+            "roofline_frac": 8.0 * C4 * (C4 - 1) * S4.shape[1] ** 3 / world / (kms4 * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+        }
+        del S4, _g4
 
     S_cpu = S.detach().cpu() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     if rank == 0:
@@ -350,8 +411,9 @@ def main():
             },
             "pairs_per_s": evals_per_s * P,
             "loss": loss.item(),
+            "rccl_ranks": dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else (1 if world == 1 else 0),
             "roofline": {
-                "bound": "mfma",
+                "bound": "valu",
                 "achieved": achieved_tf,
                 "peak": FP32_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
@@ -367,6 +429,8 @@ def main():
                         f"{bytes_eval / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS * 100:.3f}% of the 8 TB/s HBM roofline",
             },
         }
+        if c4_pairs is not None:
+            result["scaling_c4_pairs"] = c4_pairs
         if not args.no_closure and world == 1 and dtype == torch.float32:
             del S, grad
             torch.cuda.empty_cache()

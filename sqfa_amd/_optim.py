@@ -79,11 +79,29 @@ def _n_classes(data_statistics):
     return data_statistics.shape[0]
 
 
+def _broadcast_replicated_state(model):
+    """Multi-GPU fits assume bit-identical filters on every rank (each rank evaluates its tile
+    shard of the SAME feature scatters, and every rank repeats the same LBFGS update on the
+    all-reduced gradient).  Rank 0's parameters and buffers are therefore broadcast once per
+    fitting_loop call: ranks that were initialised from different seeds (the default
+    ``torch.randn`` filters) would otherwise mix inconsistent shards without any error."""
+    shard = getattr(model, "pair_shard", None) or getattr(model, "class_shard", None)
+    if shard is None or getattr(shard, "world_size", 1) <= 1:
+        return
+    import torch.distributed as dist
+    group = getattr(shard, "group", None)
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    with torch.no_grad():
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, src=src, group=group)
+
+
 def fitting_loop(model, data_statistics, max_epochs=200, lr=0.1, atol=1e-6, show_progress=True,
                  return_loss=False, **kwargs):
     """Learn the filters with LBFGS.  Same arguments, stopping rule (|dloss| < atol for three
     consecutive epochs), messages and return value as the reference's fitting_loop
     (src/sqfa/_optim.py:33-145); extra keyword arguments go to torch.optim.LBFGS."""
+    _broadcast_replicated_state(model)
     device_params = list(model.parameters())
     # the compact form is four (history x n) matrix-vector products per iteration: on the host
     # only while they are a fraction of a millisecond, otherwise on the device

@@ -383,6 +383,95 @@ def g7():
     np.savez_compressed(os.path.join(HERE, "g7_fit_c5.npz"), **out)
 
 
+# ---------------------------------------------------------------- G7b / G4b: how well-posed is "filters to 1e-5"?
+def cholesky_fisher_rao(statsA, statsB):
+    """The SAME function as the reference's fisher_rao_lower_bound (src/sqfa/distances.py:210-237),
+    evaluated through a different but mathematically equivalent route (Cholesky whitening
+    instead of the eigh whitening of src/sqfa/linalg.py:159-162), in plain torch with autograd.
+    Passed to the REFERENCE's model as distance_fun: the two reference fits then differ only by
+    rounding (1e-15 relative per evaluation), which measures how far the reference's own
+    trajectory drifts under rounding-level perturbations."""
+    EA = sqfa.distances._embed_gaussian(statsA)
+    EB = sqfa.distances._embed_gaussian(statsB)
+    L = torch.linalg.cholesky(EB)                                   # (nB,m,m)
+    Y = torch.linalg.solve_triangular(L[None], EA[:, None], upper=False)       # L^-1 A
+    M = torch.linalg.solve_triangular(L[None], Y.transpose(-1, -2), upper=False)  # L^-1 A L^-T
+    M = 0.5 * (M + M.transpose(-1, -2))
+    lam = torch.linalg.eigvalsh(M)
+    return torch.sqrt(0.5 * torch.sum(torch.log(lam) ** 2, dim=-1) + 1e-6)
+
+
+def cholesky_affine_invariant(A, B):
+    """Same idea for SecondMomentsSQFA: affine_invariant (src/sqfa/distances.py:70-89) via Cholesky."""
+    L = torch.linalg.cholesky(B)
+    Y = torch.linalg.solve_triangular(L[None], A[:, None], upper=False)
+    M = torch.linalg.solve_triangular(L[None], Y.transpose(-1, -2), upper=False)
+    M = 0.5 * (M + M.transpose(-1, -2))
+    lam = torch.linalg.eigvalsh(M)
+    return torch.sqrt(torch.sum(torch.log(lam) ** 2, dim=-1) + 1e-6)
+
+
+def _fit_record(out, key, model, stats, **fit_kwargs):
+    import time as _t
+    t0 = _t.time()
+    loss, _ = model.fit(data_statistics=stats, max_epochs=300, show_progress=False, return_loss=True, **fit_kwargs)
+    out[f"{key}_seconds"] = np.array(_t.time() - t0)
+    out[f"{key}_loss"] = loss.numpy()
+    out[f"{key}_filters"] = model.filters.detach().numpy()
+    print(key, "epochs", len(loss), "seconds", float(out[f"{key}_seconds"]), "final", float(loss[-1]), flush=True)
+
+
+def g4b():
+    """syn (C=20, D=50) K=4 fits of the reference, float64: (i) with the Cholesky-route distance
+    (reference-vs-reference drift of the fixed-step LBFGS trajectory), (ii) with
+    line_search_fn="strong_wolfe" (kwargs are forwarded to LBFGS, src/sqfa/_optim.py:78-82),
+    where the trajectory is well-posed, also for pairwise training."""
+    out = {}
+    torch.set_default_dtype(torch.float64)
+    g4_data = np.load(os.path.join(HERE, "g4_fit.npz"))
+    stats = {"means": T(g4_data["syn_mu"], torch.float64), "covariances": T(g4_data["syn_cov"], torch.float64)}
+    for model_name in ("smsqfa", "sqfa"):
+        cls = sqfa.model.SQFA if model_name == "sqfa" else sqfa.model.SecondMomentsSQFA
+        alt = cholesky_fisher_rao if model_name == "sqfa" else cholesky_affine_invariant
+        for pairwise in (False, True):
+            tag = "pairwise_K4" if pairwise else "K4"
+            model = cls(n_dim=50, n_filters=4, feature_noise=1e-2, distance_fun=alt).double()
+            model.fit_pca(data_statistics=stats)
+            _fit_record(out, f"syn_{model_name}_{tag}_cholroute", model, stats, pairwise=pairwise)
+            model = cls(n_dim=50, n_filters=4, feature_noise=1e-2).double()
+            model.fit_pca(data_statistics=stats)
+            _fit_record(out, f"syn_{model_name}_{tag}_wolfe", model, stats, pairwise=pairwise,
+                        line_search_fn="strong_wolfe")
+            model = cls(n_dim=50, n_filters=4, feature_noise=1e-2, distance_fun=alt).double()
+            model.fit_pca(data_statistics=stats)
+            _fit_record(out, f"syn_{model_name}_{tag}_wolfe_cholroute", model, stats, pairwise=pairwise,
+                        line_search_fn="strong_wolfe")
+    torch.set_default_dtype(torch.float32)
+    np.savez_compressed(os.path.join(HERE, "g4b_fit_wellposed.npz"), **out)
+
+
+def g7b():
+    """c5-shaped configuration (C=100, n_dim=3072, n_filters=16, SQFA, float64, fit_pca init):
+    (i) the reference's fit with the Cholesky-route distance_fun (drift of the reference against
+    itself under rounding-level differences; compare with G7), (ii) the reference's fit with
+    line_search_fn="strong_wolfe", (iii) the same with the Cholesky-route distance."""
+    out = {}
+    torch.set_default_dtype(torch.float64)
+    stats = c2_statistics(C=100, D=3072)
+    out["check_cov00"] = stats["covariances"][0, :4, :4].numpy()
+    path = os.path.join(HERE, "g7b_fit_c5_wellposed.npz")
+    for key, kwargs, fun in (("sqfa_cholroute", {}, cholesky_fisher_rao),
+                             ("sqfa_wolfe", {"line_search_fn": "strong_wolfe"}, None),
+                             ("sqfa_wolfe_cholroute", {"line_search_fn": "strong_wolfe"}, cholesky_fisher_rao)):
+        extra = {"distance_fun": fun} if fun is not None else {}
+        model = sqfa.model.SQFA(n_dim=3072, n_filters=16, feature_noise=0.01, **extra).double()
+        model.fit_pca(data_statistics=stats)
+        out[f"{key}_init"] = model.filters.detach().numpy().copy()
+        _fit_record(out, key, model, stats, **kwargs)
+        np.savez_compressed(path, **out)   # keep partial results
+    torch.set_default_dtype(torch.float32)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g1x", "g2", "g3", "g4", "g5"]
     for name in which:

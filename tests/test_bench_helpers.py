@@ -44,3 +44,15 @@ def test_pmc_summary_is_consistent():
     assert abs(pmc["project_kernel"]["algorithmic_bytes_per_launch"] - 4 * 1000 * 784 * 784) < 1
     assert 0.9 < pmc["project_kernel"]["hbm_bytes_per_launch"] / pmc["project_kernel"]["algorithmic_bytes_per_launch"] < 1.3
     assert np.isfinite(pmc["pair_tile_kernel"]["hbm_bytes_per_launch"])
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus N` must work without torch.distributed.run: the parent starts one
+    child per rank with RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set and relays rank 0's line."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launcher-selftest"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["world"] == 3 and line["rank"] == 0 and line["master"] == "127.0.0.1" and line["port"] > 0

@@ -81,3 +81,64 @@ def test_two_rank_pair_shard_matches_single_process():
     assert np.linalg.norm(g0 - G1["C37_m16_grad_f64"]) < 1e-9 * np.linalg.norm(g0)
     assert np.abs(fl0 - G4["syn_sqfa_K2_e3_loss"]).max() < 1e-6
     assert np.linalg.norm(F0 - G4["syn_sqfa_K2_e3_filters"]) < 1e-7 * np.linalg.norm(F0)
+
+
+def _worker_seeds(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import model_cases as mc
+        import sqfa_amd
+        from oracle_backend import oracle_pair_backend
+        from sqfa_amd import _native
+        from sqfa_amd.parallel import PairShard
+        _native._pair_backend = oracle_pair_backend   # test-only substitution
+        stats = mc.fit_stats("syn", torch.float64, torch.device("cpu"))
+        torch.manual_seed(100 + rank)                  # every rank draws DIFFERENT random filters
+        torch.set_default_dtype(torch.float64)
+        model = sqfa_amd.model.SQFA(n_dim=50, n_filters=2, feature_noise=1e-3).double()
+        init = model.parametrizations.filters.original.detach().clone().numpy()   # the raw parameter
+        model.pair_shard = PairShard()
+        fl, _ = model.fit(data_statistics=stats, max_epochs=2, show_progress=False, return_loss=True)
+        q.put((rank, init, fl.numpy(), model.filters.detach().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_fit_starts_from_rank0_parameters():
+    """ranks seeded differently must not silently mix shards of different filters --
+    fitting_loop broadcasts rank 0's parameters, so both ranks walk rank 0's trajectory."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_seeds, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, init0, fl0, F0), (_, init1, fl1, F1) = results
+    assert not np.array_equal(init0, init1)           # the ranks really started apart
+    assert np.array_equal(fl0, fl1) and np.array_equal(F0, F1)
+    # and the trajectory is rank 0's: a single-process fit from rank 0's initial filters
+    import model_cases as mc
+    import sqfa_amd
+    from oracle_backend import oracle_pair_backend
+    from sqfa_amd import _native
+    saved = _native._pair_backend
+    _native._pair_backend = oracle_pair_backend
+    try:
+        stats = mc.fit_stats("syn", torch.float64, torch.device("cpu"))
+        model = sqfa_amd.model.SQFA(n_dim=50, n_filters=2, feature_noise=1e-3).double()
+        with torch.no_grad():
+            model.parametrizations.filters.original.copy_(torch.tensor(init0))
+        fl, _ = model.fit(data_statistics=stats, max_epochs=2, show_progress=False, return_loss=True)
+    finally:
+        _native._pair_backend = saved
+    assert np.abs(fl.numpy() - fl0).max() < 1e-6   # the loss list is a default-dtype (float32) tensor here
