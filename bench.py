@@ -257,7 +257,8 @@ def spawn_ranks(n, argv):
         except subprocess.TimeoutExpired:  # rank 0 is gone: a rank still alive is stuck in a collective
             p.kill()
             codes.append(p.wait())
-    sys.stdout.write(out.decode())
+    for line in out.decode().splitlines():   # stdout carries the JSON line only (libraries' chatter -> stderr)
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     return max(abs(c) for c in codes)
 

@@ -106,6 +106,24 @@ int sqfa_airm_pairwise(const void *A, int nA, const void *B, int nB, int m, int 
                        void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * Backward of the generalized eigenvalues themselves (the reference's generalized_eigenvalues,
+ * src/sqfa/linalg.py:48-70, is autograd-transparent and its tutorial builds custom distance_funs
+ * on it, docs/source/tutorials/distances.md:127-178): gradient of
+ *     sum_{i,j,k} eig_weights[i,j,k] * lambda_k(A_i, B_j)
+ * with respect to A and B, in closed form (d lambda_k/dA = u_k u_k^T, d lambda_k/dB = -lambda_k u_k u_k^T
+ * for the generalized eigenvectors U, U^T B U = I).
+ *   eig_weights  (nA, nB, m) dtype, indexed like sqfa_airm_pairwise's eig_out of the SAME inputs
+ *                (its unsorted column order is a deterministic function of the inputs; a caller that
+ *                sorts the eigenvalues scatters its upstream gradient back through the permutation)
+ *   gradA_out (nA,m,m), gradB_out (nB,m,m; cross mode); SELF mode (B NULL, nB 0): eig_weights[j,i,k]
+ *                weighs the mirrored value 1/lambda_k and the result is the gradient wrt the shared batch.
+ *   workspace as for sqfa_airm_pairwise.
+ */
+int sqfa_airm_eigenvalues_backward(const void *A, int nA, const void *B, int nB, int m, int dtype,
+                                   const void *eig_weights, void *gradA_out, void *gradB_out,
+                                   void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * T_c = Psi_c F^T for c = 0..C-1: the streaming half of the projection S_c = F Psi_c F^T of the
  * class scatter matrices into feature space.  Replaces conjugate_matrix
  * (src/sqfa/linalg.py:19-45) as called by transform_scatters (src/sqfa/model.py:172-188):
@@ -132,6 +150,26 @@ int sqfa_project_scatters(const void *F, int K, int D, const void *Psi, int C, i
 int sqfa_feature_scatters(const void *F, int K, int D, const void *T, int C, int dtype, void *S_out, void *stream);
 int sqfa_feature_scatters_backward(const void *G, const void *T, int C, int D, int K, int dtype, int n_groups,
                                    void *partial_out, void *stream);
+
+/*
+ * Per-pair Gaussian terms behind the reference's other distance_fun operators -- bhattacharyya
+ * (src/sqfa/distances.py:240-280), mahalanobis[_sq] (:283-361), hellinger (:364-393),
+ * fisher_rao_same_cov (:396-432) -- which all reduce to, with Sbar_ij = (Sigma_i + Sigma_j)/2 and
+ * delta_ij = mu_i - mu_j:
+ *     Q_ij  = delta^T Sbar^-1 delta          LD_ij = log det Sbar
+ * The reference materialises the (nA,nB,K,K) tensor of mean covariances and runs batched inv / logdet
+ * on it; here one lane group factorises one pair at a time and only (nA,nB) outputs exist.
+ *   muA (nA,m), covA (nA,m,m), muB (nB,m), covB (nB,m,m): row-major, dtype; m <= 64
+ *   Q_out, LD_out   (nA,nB) dtype, either may be NULL
+ *   gQ, gLD         (nA,nB) dtype upstream gradients (either may be NULL), used when gcovA_out != NULL:
+ *   gmuA_out (nA,m), gcovA_out (nA,m,m): gradient of sum_ij (gQ_ij Q_ij + gLD_ij LD_ij) wrt muA / covA
+ *                   (full symmetric matrices).  Both NULL = forward only.
+ * The B-side gradient is the same call with A and B swapped and gQ / gLD transposed; when B is A the
+ * caller passes gQ + gQ^T, gLD + gLD^T and takes the A side as the total.  Deterministic (no atomics).
+ */
+int sqfa_gauss_pair_terms(const void *muA, const void *covA, int nA, const void *muB, const void *covB, int nB,
+                          int m, int dtype, const void *gQ, const void *gLD, void *Q_out, void *LD_out,
+                          void *gmuA_out, void *gcovA_out, void *stream);
 
 /* Introspection (benchmarks / development; not needed by a reference-side binding).
  *

@@ -102,6 +102,22 @@ def generalized_eigenvalues(A, B):
     return out
 
 
+def eigenvalue_weight_gradient(A, B, weights):
+    """Gradient of sum_ijk weights[i,j,k] * lam_k(A_i, B_j) (lam descending, as returned by
+    generalized_eigenvalues) wrt A and B: dlam/dA = u u^T, dlam/dB = -lam u u^T."""
+    A = np.asarray(A, dtype=np.float64)
+    B = np.asarray(B, dtype=np.float64)
+    Linv = np.linalg.inv(np.linalg.cholesky(B))
+    gA, gB = np.zeros_like(A), np.zeros_like(B)
+    for i in range(A.shape[0]):
+        for j in range(B.shape[0]):
+            lam, U = _pair_terms(A[i], Linv[j])     # ascending
+            w = np.asarray(weights[i, j], dtype=np.float64)[::-1]
+            gA[i] += (U * w) @ U.T
+            gB[j] += -(U * (w * lam)) @ U.T
+    return gA, gB
+
+
 def embed_gaussian(means, covariances):
     means = np.asarray(means, dtype=np.float64)
     cov = np.asarray(covariances, dtype=np.float64)

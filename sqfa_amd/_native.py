@@ -159,27 +159,158 @@ class PairwiseLoss(torch.autograd.Function):
         return grad * gloss, None, None, None, None, None, None
 
 
+def hip_eigenvalues_backward(A, B, eig_weights):
+    """sqfa_airm_eigenvalues_backward on the current stream: gradients of sum(eig_weights * eig)
+    wrt A (nA,m,m) and B (nB,m,m), `eig_weights` (nA,nB,m) in the kernel's unsorted column order."""
+    lib = _lib.load()
+    if not A.is_cuda:
+        raise RuntimeError("sqfa_amd computes generalized eigenvalues on the GPU only (no CPU fallback)")
+    A = A.detach().contiguous()
+    B = B.detach().contiguous()
+    W = eig_weights.detach().to(A.dtype).contiguous()
+    nA, nB, m = A.shape[0], B.shape[0], A.shape[-1]
+    code = _dtype_code(A)
+    nbytes = lib.sqfa_airm_workspace_bytes(nA, nB, m, code)
+    if nbytes == 0:
+        raise _lib.NativeLibraryError("sqfa_airm_workspace_bytes rejected the problem shape")
+    with torch.cuda.device(A.device):
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=A.device)
+        gA, gB = torch.empty_like(A), torch.empty_like(B)
+        stream = torch.cuda.current_stream(A.device).cuda_stream
+        status = lib.sqfa_airm_eigenvalues_backward(_ptr(A), nA, _ptr(B), nB, m, code, _ptr(W), _ptr(gA), _ptr(gB),
+                                                    _ptr(ws), nbytes, ctypes.c_void_p(stream))
+    _lib.check(status, "sqfa_airm_eigenvalues_backward")
+    return gA, gB
+
+
+_eig_backward_backend = hip_eigenvalues_backward
+
+
+class GeneralizedEigenvalues(torch.autograd.Function):
+    """(nA,nB,m) generalized eigenvalues of every pair (A_i, B_j), descending, differentiable
+    (the reference's generalized_eigenvalues is autograd-transparent, src/sqfa/linalg.py:48-70).
+    The kernel returns the eigenvalues in its own (deterministic) column order; the sort
+    permutation is kept and the upstream gradient is scattered back through it, then one
+    more launch evaluates sum_k w_k dlambda_k/d(A,B) in closed form (u u^T, -lambda u u^T)."""
+
+    @staticmethod
+    def forward(ctx, A, B):
+        out = _pair_backend(A, B, scale=1.0, eps=EPSILON, sqrt_mode=False, weights=None,
+                            uniform_weight=0.0, shard=(0, 1), want_loss=False, want_grad=False,
+                            want_dist=False, want_eig=True)
+        lam, order = torch.sort(out["eig"], dim=-1, descending=True)
+        ctx.save_for_backward(A, B, order)
+        return lam
+
+    @staticmethod
+    def backward(ctx, g_lam):
+        A, B, order = ctx.saved_tensors
+        w = torch.zeros_like(g_lam).scatter_(-1, order, g_lam)
+        gA, gB = _eig_backward_backend(A, B, w)
+        return gA, gB
+
+
 def generalized_eigenvalues_raw(A, B):
-    """(nA,nB,m) generalized eigenvalues of (A_i, B_j), descending.  Not differentiable."""
-    out = _pair_backend(A, B, scale=1.0, eps=EPSILON, sqrt_mode=False, weights=None,
-                        uniform_weight=0.0, shard=(0, 1), want_loss=False, want_grad=False,
-                        want_dist=False, want_eig=True)
-    return torch.sort(out["eig"], dim=-1, descending=True).values
+    """(nA,nB,m) generalized eigenvalues of (A_i, B_j), descending; differentiable wrt A and B."""
+    return GeneralizedEigenvalues.apply(A, B)
+
+
+# ------------------------------------------------------------------------------------------
+# Gaussian pair terms (bhattacharyya / mahalanobis / hellinger / fisher_rao_same_cov)
+
+
+def hip_gauss_terms(muA, covA, muB, covB, gQ=None, gLD=None, want_outputs=True, want_grad=False):
+    """sqfa_gauss_pair_terms on the current stream.  Returns (Q, LD, gmuA, gcovA) (None where not requested)."""
+    lib = _lib.load()
+    if not covA.is_cuda:
+        raise RuntimeError("sqfa_amd's native Gaussian pair terms run on the GPU only")
+    muA, covA, muB, covB = (t.detach().contiguous() for t in (muA, covA, muB, covB))
+    nA, nB, m = covA.shape[0], covB.shape[0], covA.shape[-1]
+    code = _dtype_code(covA)
+    dev, dt = covA.device, covA.dtype
+    with torch.cuda.device(dev):
+        Q = torch.empty((nA, nB), dtype=dt, device=dev) if want_outputs else None
+        LD = torch.empty((nA, nB), dtype=dt, device=dev) if want_outputs else None
+        gmu = torch.empty((nA, m), dtype=dt, device=dev) if want_grad else None
+        gcov = torch.empty((nA, m, m), dtype=dt, device=dev) if want_grad else None
+        gQ = gQ.detach().to(dt).contiguous() if gQ is not None else None
+        gLD = gLD.detach().to(dt).contiguous() if gLD is not None else None
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        status = lib.sqfa_gauss_pair_terms(_ptr(muA), _ptr(covA), nA, _ptr(muB), _ptr(covB), nB, m, code,
+                                           _ptr(gQ), _ptr(gLD), _ptr(Q), _ptr(LD), _ptr(gmu), _ptr(gcov), stream)
+    _lib.check(status, "sqfa_gauss_pair_terms")
+    return Q, LD, gmu, gcov
+
+
+GAUSS_MAX_DIM = 64
+
+
+class GaussPairTerms(torch.autograd.Function):
+    """Q_ij = (mu_i-mu_j)^T Sbar_ij^-1 (mu_i-mu_j) and LD_ij = logdet Sbar_ij with
+    Sbar_ij = (Sigma_i + Sigma_j)/2, as differentiable (nA,nB) matrices -- the pair-dependent part of
+    the reference's bhattacharyya / mahalanobis / hellinger / fisher_rao_same_cov
+    (src/sqfa/distances.py:240-432), without the (nA,nB,K,K) tensor those build.  `same` marks the
+    self case (B is A): one backward launch with symmetrised upstream gradients."""
+
+    @staticmethod
+    def forward(ctx, muA, covA, muB, covB, same):
+        Q, LD, _, _ = hip_gauss_terms(muA, covA, muB, covB)
+        ctx.save_for_backward(muA, covA, muB, covB)
+        ctx.same = same
+        return Q, LD
+
+    @staticmethod
+    def backward(ctx, gQ, gLD):
+        muA, covA, muB, covB = ctx.saved_tensors
+        if ctx.same:
+            _, _, gmu, gcov = hip_gauss_terms(muA, covA, muA, covA, gQ + gQ.t(), gLD + gLD.t(),
+                                              want_outputs=False, want_grad=True)
+            return gmu, gcov, None, None, None
+        _, _, gmuA, gcovA = hip_gauss_terms(muA, covA, muB, covB, gQ, gLD, want_outputs=False, want_grad=True)
+        _, _, gmuB, gcovB = hip_gauss_terms(muB, covB, muA, covA, gQ.t(), gLD.t(), want_outputs=False, want_grad=True)
+        return gmuA, gcovA, gmuB, gcovB, None
 
 
 # ------------------------------------------------------------------------------------------
 # projection of the class scatter matrices (the HBM-bound stage around the pair kernel)
 
 
+_symmetry_checked = {}   # (data_ptr, _version, shape, dtype) -> bool, for the scatter tensors seen most recently
+
+
+def _is_symmetric_batch(scatters):
+    """The streaming kernel forms T = Psi^T F^T, which equals the reference's Psi F^T only for
+    symmetric Psi (covariance / second-moment matrices are; conjugate_matrix itself is general,
+    src/sqfa/linalg.py:19-45).  Checked ONCE per tensor identity (one pass over Psi and one host
+    read), outside any graph capture; asymmetry at rounding level (a GEMM-built X^T X) passes."""
+    key = (scatters.data_ptr(), scatters._version, tuple(scatters.shape), scatters.dtype)
+    hit = _symmetry_checked.get(key)
+    if hit is not None:
+        return hit
+    if torch.cuda.is_current_stream_capturing():
+        return False  # never seen outside a capture: take the general torch expression
+    tol = 1e-5 if scatters.dtype == torch.float32 else 1e-12
+    with torch.no_grad():
+        asym = (scatters - scatters.transpose(-2, -1)).abs().amax()
+        ok = bool(asym <= tol * scatters.abs().amax())
+    if len(_symmetry_checked) > 16:
+        _symmetry_checked.clear()
+    _symmetry_checked[key] = ok
+    return ok
+
+
 def native_projection_supported(scatters, filters):
-    """The streaming kernel handles float32/float64 (C,D,D) scatters on the GPU with D % 4 == 0
-    and up to 64 filters; anything else keeps the plain torch expression."""
+    """The streaming kernel handles SYMMETRIC float32/float64 (C,D,D) scatters on the GPU with
+    D % 4 == 0, 16-byte aligned storage and up to 64 filters; anything else keeps the plain torch
+    expression (conjugate_matrix)."""
     return (
         scatters.is_cuda and filters.is_cuda and scatters.dtype in (torch.float32, torch.float64)
         and filters.dtype == scatters.dtype
         and scatters.dim() == 3 and filters.dim() == 2 and scatters.shape[-1] % 4 == 0
         and filters.shape[0] <= 64 and filters.shape[0] <= filters.shape[1]
         and scatters.shape[-1] == scatters.shape[-2] == filters.shape[1] and not scatters.requires_grad
+        and scatters.is_contiguous() and scatters.data_ptr() % 16 == 0
+        and _is_symmetric_batch(scatters)
     )
 
 

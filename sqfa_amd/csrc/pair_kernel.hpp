@@ -43,6 +43,8 @@ struct PairParams {
   const void* Linv;   // inverse Cholesky factor of each B class, identity padded: [nB][MR*MR] row-major, or
                       // [nB][MR(MR+1)/2] packed lower triangle (row r at r(r+1)/2) for MR >= 32 (PairCfg::PACK_LINV)
   const void* W;      // optional (nA,nB) pair weights, or nullptr
+  const void* EW;     // optional (nA,nB,m) per-eigenvalue weights in eig_out's (unsorted column) order, or nullptr:
+                      // the gradient is then that of  sum_ijk EW_ijk lambda_k(A_i,B_j)  (backward of generalized_eigenvalues)
   void* slab_grad;    // [nbi*nbj][TI+tj][TRI]  lower triangles: TI A-side rows, then tj B-side rows per tile
   void* slab_loss;    // [nbi*nbj]
   int* slab_flag;     // [nbi*nbj][2]  {NaN count, inf count}
@@ -501,7 +503,8 @@ struct PairCfg {
 template <typename Cfg>
 __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel(
     const PairParams p, const typename Cfg::type* __restrict__ LT,
-    const typename Cfg::type* __restrict__ LinvAll, const typename Cfg::type* __restrict__ Wt) {
+    const typename Cfg::type* __restrict__ LinvAll, const typename Cfg::type* __restrict__ Wt,
+    const typename Cfg::type* __restrict__ EWt) {
   using T = typename Cfg::type;
   using R = Real<T>;
   constexpr int MR = Cfg::MR, G = Cfg::G, CPL = Cfg::CPL, TI = Cfg::TI;
@@ -766,6 +769,22 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
         coefB[c] = -q;
         coefA[c] = q / lam[c];
       }
+      if (EWt != nullptr) {
+        // backward of the eigenvalues themselves: d lambda_k/dA = u u^T = u~ u~^T / lambda_k,
+        // d lambda_k/dB = -lambda_k u u^T = -u~ u~^T  (u~ = sigma_k u).  Self mode also carries the
+        // mirrored entry eig[j,i,k] = 1/lambda_k, whose derivative is -1/lambda_k^2.
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          const int col = c * G + g;
+          T wk = T(0);
+          if (valid && col < p.m) {
+            wk = EWt[((size_t)io * p.nB + j) * p.m + col];
+            if (p.self_mode) wk -= EWt[((size_t)j * p.nB + io) * p.m + col] / (lam[c] * lam[c]);
+          }
+          coefB[c] = -wk;
+          coefA[c] = wk / lam[c];
+        }
+      }
       // u~ = L_j^-T y in place: u~[r] = sum_{q>=r} Linv[q][r] y[q], rows in ascending order
 #pragma unroll
       for (int r = 0; r < MR; ++r) {
@@ -844,7 +863,7 @@ hipError_t launch_pair_tiles(const PairParams& p, hipStream_t stream) {
   dim3 grid((unsigned)n_tiles, 1, 1);
   using T = typename Cfg::type;
   hipLaunchKernelGGL((pair_tile_kernel<Cfg>), grid, dim3(Cfg::THREADS), 0, stream, p, static_cast<const T*>(p.LT),
-                     static_cast<const T*>(p.Linv), static_cast<const T*>(p.W));
+                     static_cast<const T*>(p.Linv), static_cast<const T*>(p.W), static_cast<const T*>(p.EW));
   return hipGetLastError();
 }
 

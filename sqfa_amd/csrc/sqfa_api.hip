@@ -405,11 +405,11 @@ size_t sqfa_airm_workspace_bytes(int nA, int nB, int m, int dtype) {
   return layout(nA, nBeff, g, dtype == SQFA_F32 ? 4 : 8, nB == 0 ? 1 : 0).total;
 }
 
-int sqfa_airm_pairwise(const void* A, int nA, const void* B, int nB, int m, int dtype, double scale,
-                       double eps, int sqrt_mode, const void* pair_weights, double uniform_weight,
-                       int shard_index, int shard_count, void* loss_out, void* gradA_out,
-                       void* gradB_out, void* dist_out, void* eig_out, int* nonfinite_out,
-                       void* workspace, size_t workspace_bytes, void* stream_) {
+static int pairwise_impl(const void* A, int nA, const void* B, int nB, int m, int dtype, double scale,
+                         double eps, int sqrt_mode, const void* pair_weights, double uniform_weight,
+                         int shard_index, int shard_count, void* loss_out, void* gradA_out,
+                         void* gradB_out, void* dist_out, void* eig_out, int* nonfinite_out,
+                         void* workspace, size_t workspace_bytes, void* stream_, const void* eig_weights) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   g_last_error[0] = 0;
   if (A == nullptr || nA < 1 || m < 1 || nB < 0 || workspace == nullptr) return fail(SQFA_ERR_BAD_ARGUMENT, "null/size argument", hipSuccess);
@@ -439,6 +439,7 @@ int sqfa_airm_pairwise(const void* A, int nA, const void* B, int nB, int m, int 
   p.LT = ws + w.off_lt;
   p.Linv = ws + w.off_linv;
   p.W = pair_weights;
+  p.EW = eig_weights;
   p.slab_grad = ws + w.off_slab;
   p.slab_loss = ws + w.off_loss;
   p.slab_flag = reinterpret_cast<int*>(ws + w.off_flag);
@@ -521,6 +522,27 @@ int sqfa_airm_pairwise(const void* A, int nA, const void* B, int nB, int m, int 
   e = hipGetLastError();
   if (e != hipSuccess) return fail(SQFA_ERR_LAUNCH, "finalize_kernel", e);
   return SQFA_OK;
+}
+
+int sqfa_airm_pairwise(const void* A, int nA, const void* B, int nB, int m, int dtype, double scale,
+                       double eps, int sqrt_mode, const void* pair_weights, double uniform_weight,
+                       int shard_index, int shard_count, void* loss_out, void* gradA_out,
+                       void* gradB_out, void* dist_out, void* eig_out, int* nonfinite_out,
+                       void* workspace, size_t workspace_bytes, void* stream_) {
+  return pairwise_impl(A, nA, B, nB, m, dtype, scale, eps, sqrt_mode, pair_weights, uniform_weight, shard_index,
+                       shard_count, loss_out, gradA_out, gradB_out, dist_out, eig_out, nonfinite_out, workspace,
+                       workspace_bytes, stream_, nullptr);
+}
+
+int sqfa_airm_eigenvalues_backward(const void* A, int nA, const void* B, int nB, int m, int dtype,
+                                   const void* eig_weights, void* gradA_out, void* gradB_out,
+                                   void* workspace, size_t workspace_bytes, void* stream_) {
+  if (eig_weights == nullptr || gradA_out == nullptr) {
+    g_last_error[0] = 0;
+    return fail(SQFA_ERR_BAD_ARGUMENT, "eig_weights / gradA_out", hipSuccess);
+  }
+  return pairwise_impl(A, nA, B, nB, m, dtype, 1.0, 0.0, 0, nullptr, 0.0, 0, 1, nullptr, gradA_out, gradB_out,
+                       nullptr, nullptr, nullptr, workspace, workspace_bytes, stream_, eig_weights);
 }
 
 }  // extern "C"

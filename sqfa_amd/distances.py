@@ -134,9 +134,11 @@ def fisher_rao_lower_bound(statistics_A, statistics_B):
 def log_euclidean_sq(A, B):
     """|| log A_i - log B_j ||_F^2 (reference: src/sqfa/distances.py:92-116)."""
     LA = spd_log(_batch_of_matrices(A))
-    LB = spd_log(B)
-    diff = LA[:, None] - LB[None]
-    return torch.squeeze((diff * diff).sum(dim=(-2, -1)))
+    LB = spd_log(_batch_of_matrices(B))
+    # || log A_i - log B_j ||_F^2 as exact pairwise distances between the flattened logarithms: the
+    # reference's (nA,nB,m,m) difference tensor is never formed (C per-class logarithms + one (nA,nB) pass)
+    d = torch.cdist(LA.flatten(1)[None], LB.flatten(1)[None], compute_mode="donot_use_mm_for_euclid_dist")[0]
+    return torch.squeeze(d * d)
 
 
 def log_euclidean(A, B):
@@ -144,34 +146,50 @@ def log_euclidean(A, B):
     return torch.sqrt(log_euclidean_sq(A, B) + EPSILON)
 
 
-def _gaussian_pairs(statistics_A, statistics_B):
+def _gaussian_inputs(statistics_A, statistics_B):
     muA = _batch_of_vectors(statistics_A["means"])
     covA = _batch_of_matrices(statistics_A["covariances"])
     muB = _batch_of_vectors(statistics_B["means"])
     covB = _batch_of_matrices(statistics_B["covariances"])
+    return muA, covA, muB, covB
+
+
+def _gauss_pair_terms(statistics_A, statistics_B):
+    """(Q, LD, ldA, ldB): Q_ij = delta^T Sbar^-1 delta, LD_ij = logdet Sbar for the pair's mean
+    covariance Sbar = (Sigma_i + Sigma_j)/2, and the per-class log-determinants.  GPU tensors go through the native pair kernel
+    (one lane group per pair; nothing of size (nA,nB,K,K) is formed); CPU tensors keep the torch
+    expression of the reference."""
+    muA, covA, muB, covB = _gaussian_inputs(statistics_A, statistics_B)
+    if covA.is_cuda and covA.shape[-1] <= _native.GAUSS_MAX_DIM and covA.dtype in (torch.float32, torch.float64):
+        same = (statistics_A["means"] is statistics_B["means"]
+                and statistics_A["covariances"] is statistics_B["covariances"])
+        if same:
+            Q, LD = _native.GaussPairTerms.apply(muA, covA, muA, covA, True)
+            # Sbar_ii = Sigma_i exactly, so the diagonal IS the per-class log-determinant, from the same
+            # arithmetic as the pair terms: D_ii and its (for hellinger 500x amplified) gradient then
+            # cancel exactly, as they do in the reference (identical LU of mean_cov and cov on the diagonal)
+            ld = torch.diagonal(LD)
+            return Q, LD, ld, ld
+        Q, LD = _native.GaussPairTerms.apply(muA, covA, muB.to(covA.dtype), covB.to(covA.dtype), False)
+        return Q, LD, torch.logdet(covA), torch.logdet(covB)
     mid = 0.5 * (covA[:, None] + covB[None])
     delta = muA[:, None] - muB[None]
-    return covA, covB, mid, delta
-
-
-def _quad_form_inv(mid, delta):
     sol = torch.linalg.solve(mid, delta.unsqueeze(-1)).squeeze(-1)
-    return (delta * sol).sum(-1)
+    return (delta * sol).sum(-1), torch.logdet(mid), torch.logdet(covA), torch.logdet(covB)
 
 
 def bhattacharyya(statistics_A, statistics_B):
-    """Bhattacharyya distance between Gaussians (reference: src/sqfa/distances.py:240-280)."""
-    covA, covB, mid, delta = _gaussian_pairs(statistics_A, statistics_B)
-    mean_term = _quad_form_inv(mid, delta) / 8
-    det_term = 0.5 * (torch.logdet(mid) - 0.5 * (torch.logdet(covA)[:, None] + torch.logdet(covB)[None]))
-    return torch.squeeze(mean_term + det_term)
+    """Bhattacharyya distance between Gaussians (reference: src/sqfa/distances.py:240-280):
+    Q/8 + (logdet Sbar - (logdet Sigma_i + logdet Sigma_j)/2)/2."""
+    Q, LD, ldA, ldB = _gauss_pair_terms(statistics_A, statistics_B)
+    det_term = 0.5 * (LD - 0.5 * (ldA[:, None] + ldB[None]))
+    return torch.squeeze(Q / 8 + det_term)
 
 
 def mahalanobis_sq(statistics_A, statistics_B):
     """Squared Mahalanobis distance under the pair's mean covariance
-    (reference: src/sqfa/distances.py:283-332)."""
-    _, _, mid, delta = _gaussian_pairs(statistics_A, statistics_B)
-    return _quad_form_inv(mid, delta)
+    (reference: src/sqfa/distances.py:283-332; like the reference, not squeezed)."""
+    return _gauss_pair_terms(statistics_A, statistics_B)[0]
 
 
 def mahalanobis(statistics_A, statistics_B):
@@ -188,4 +206,5 @@ def fisher_rao_same_cov(statistics_A, statistics_B):
     """Exact Fisher-Rao distance for a shared covariance (the pair's mean covariance):
     sqrt(2) * acosh(1 + mahalanobis^2 / 4) (reference: src/sqfa/distances.py:396-432)."""
     d2 = mahalanobis_sq(statistics_A, statistics_B)
-    return (2.0 ** 0.5) * torch.acosh(1 + d2 / 4)
+    # like the reference, sqrt(2) is a default-dtype tensor (float32-rounded under the float32 default)
+    return torch.sqrt(torch.tensor(2.0)).to(d2.device) * torch.acosh(1 + d2 / 4)

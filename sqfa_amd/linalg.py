@@ -47,7 +47,8 @@ def conjugate_matrix(A, B):
 def generalized_eigenvalues(A, B):
     """Generalized eigenvalues of every pair (A_i, B_j), descending, shape (nA,nB,m) with
     unit batch dims squeezed (reference: src/sqfa/linalg.py:48-70).  Computed by the HIP
-    pair kernel (Cholesky whitening + one-sided Jacobi); values only, no autograd."""
+    pair kernel (Cholesky whitening + one-sided Jacobi); differentiable (closed-form backward
+    through a second launch, _native.GeneralizedEigenvalues)."""
     A3 = A[None] if A.dim() == 2 else A
     B3 = B[None] if B.dim() == 2 else B
     lam = _native.generalized_eigenvalues_raw(A3, B3)

@@ -50,7 +50,7 @@ def class_statistics(points, labels, estimator="empirical"):
     shrinkage.  Same estimators (centre first, then 1/(n-1)), different summation order."""
     if estimator not in ("empirical", "oas"):
         raise ValueError("estimator must be 'empirical' or 'oas'")
-    labels = labels.to(points.device)
+    labels = labels.to(points.device).long()   # the reference accepts float labels too (it compares with ==)
     n_classes = int(labels.max()) + 1
     d = points.shape[-1]
     order = torch.sort(labels, stable=True).indices

@@ -118,6 +118,14 @@ def g1x():
                 gA, gB = torch.autograd.grad(loss, (At, Bt), retain_graph=True)
                 out[f"{key}_gA_{name}_{tag}"] = gA.numpy()
                 out[f"{key}_gB_{name}_{tag}"] = gB.numpy()
+            # gradient of a weighted sum of the eigenvalues themselves (generalized_eigenvalues is
+            # autograd-transparent in the reference); weights from a generator of their own so that
+            # the arrays above stay bit-identical to the first generation
+            Wl = np.random.default_rng(7700 + 100 * nA + 10 * nB + m).standard_normal(tuple(lam.shape))
+            out[f"{key}_Wlam"] = Wl
+            gA, gB = torch.autograd.grad(torch.sum(T(Wl, dt) * lam), (At, Bt), retain_graph=True)
+            out[f"{key}_gA_lam_{tag}"] = gA.numpy()
+            out[f"{key}_gB_lam_{tag}"] = gB.numpy()
     np.savez_compressed(os.path.join(HERE, "g1x_airm_cross.npz"), **out)
 
 
@@ -469,6 +477,138 @@ def g7b():
         out[f"{key}_init"] = model.filters.detach().numpy().copy()
         _fit_record(out, key, model, stats, **kwargs)
         np.savez_compressed(path, **out)   # keep partial results
+    torch.set_default_dtype(torch.float32)
+
+
+# ---------------------------------------------------------------- G5b: the other distance_fun operators, with gradients
+GAUSS_OPS = ("bhattacharyya", "mahalanobis_sq", "mahalanobis", "hellinger", "fisher_rao_same_cov")
+
+
+def g5b():
+    """Values and gradients of the reference's remaining distance operators
+    (src/sqfa/distances.py:92-138, 240-432) for self (A is B) and cross batches, float64 and float32:
+    loss = sum(W * D) with a random non-symmetric W; gradients wrt means and covariances."""
+    rng = np.random.default_rng(5151)
+    out = {}
+    cases = [(5, 0, 4), (4, 7, 3), (12, 0, 16), (100, 0, 8), (6, 0, 33), (9, 0, 1), (3, 5, 17), (40, 0, 2)]
+    out["cases"] = np.array(cases)
+    for (nA, nB, K) in cases:
+        key = f"A{nA}_B{nB}_K{K}"
+        covA, muA = random_spd(rng, nA, K, lo=0.05), 0.8 * rng.standard_normal((nA, K))
+        out[f"{key}_covA"], out[f"{key}_muA"] = covA, muA
+        if nB:
+            covB, muB = random_spd(rng, nB, K, lo=0.05), 0.8 * rng.standard_normal((nB, K))
+            out[f"{key}_covB"], out[f"{key}_muB"] = covB, muB
+        W = rng.standard_normal((nA, nB or nA))
+        out[f"{key}_W"] = W
+        for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            def leaves():
+                a = {"means": T(muA, dt).requires_grad_(True), "covariances": T(covA, dt).requires_grad_(True)}
+                b = a if not nB else {"means": T(muB, dt).requires_grad_(True), "covariances": T(covB, dt).requires_grad_(True)}
+                return a, b
+            for name in GAUSS_OPS + ("log_euclidean_sq", "log_euclidean"):
+                a, b = leaves()
+                fn = getattr(sqfa.distances, name)
+                D = fn(a["covariances"], b["covariances"]) if name.startswith("log_") else fn(a, b)
+                out[f"{key}_{name}_{tag}"] = D.detach().numpy()
+                loss = torch.sum(T(W, dt).reshape(D.shape) * D)
+                wrt = [a["covariances"]] + ([b["covariances"]] if nB else [])
+                if not name.startswith("log_"):
+                    wrt += [a["means"]] + ([b["means"]] if nB else [])
+                grads = torch.autograd.grad(loss, wrt)
+                names = ["gcovA"] + (["gcovB"] if nB else [])
+                if not name.startswith("log_"):
+                    names += ["gmuA"] + (["gmuB"] if nB else [])
+                for gname, g in zip(names, grads):
+                    out[f"{key}_{name}_{gname}_{tag}"] = g.numpy()
+    np.savez_compressed(os.path.join(HERE, "g5b_other_operators.npz"), **out)
+
+
+# ---------------------------------------------------------------- G5c: class statistics at scale
+def ragged_points(C=1000, d=5, seed=606):
+    """Ragged class sizes (2..41 points), float32-representable coordinates, shuffled; regenerated
+    from the seed by the tests (numpy Generator: identical on every platform)."""
+    rng = np.random.default_rng(seed)
+    sizes = rng.integers(2, 42, size=C)
+    y = np.repeat(np.arange(C), sizes)
+    X = (rng.standard_normal((len(y), d)) * rng.uniform(0.5, 2.0, size=(1, d)) + 0.3 * rng.standard_normal((C, d))[y])
+    X = X.astype(np.float32).astype(np.float64)
+    perm = rng.permutation(len(y))
+    return X[perm], y[perm]
+
+
+def g5c():
+    """class_statistics of the reference (src/sqfa/statistics.py:8-124) on a ragged 1000-class set,
+    both estimators, float64; plus a float-label call (the reference accepts float labels)."""
+    out = {}
+    torch.set_default_dtype(torch.float64)
+    X, y = ragged_points()
+    out["check_X0"] = X[:3].copy()
+    for est in ("empirical", "oas"):
+        st = sqfa.statistics.class_statistics(T(X, torch.float64), torch.tensor(y), estimator=est)
+        for k, v in st.items():
+            out[f"{est}_{k}"] = v.numpy()
+    st = sqfa.statistics.class_statistics(T(X, torch.float64), torch.tensor(y, dtype=torch.float64), estimator="empirical")
+    out["float_labels_means"] = st["means"].numpy()
+    torch.set_default_dtype(torch.float32)
+    np.savez_compressed(os.path.join(HERE, "g5c_class_statistics.npz"), **out)
+
+
+def g4c():
+    """Ensemble estimate of the reference's own sensitivity on the syn K=4 fits: the reference fitted
+    from 8 copies of the fit_pca initialisation perturbed by 1e-14 relative noise (raw parameter),
+    with its default distance functions, fixed-step and strong-Wolfe LBFGS.  The spread of the
+    learned filters over the ensemble is the yardstick for "filters match" on these fits."""
+    out = {}
+    torch.set_default_dtype(torch.float64)
+    g4_data = np.load(os.path.join(HERE, "g4_fit.npz"))
+    stats = {"means": T(g4_data["syn_mu"], torch.float64), "covariances": T(g4_data["syn_cov"], torch.float64)}
+    rng = np.random.default_rng(4343)
+    for model_name in ("smsqfa", "sqfa"):
+        cls = sqfa.model.SQFA if model_name == "sqfa" else sqfa.model.SecondMomentsSQFA
+        for opt, kwargs in (("fixed", {}), ("wolfe", {"line_search_fn": "strong_wolfe"})):
+            filters, finals, epochs = [], [], []
+            for sample in range(8):
+                model = cls(n_dim=50, n_filters=4, feature_noise=1e-2).double()
+                model.fit_pca(data_statistics=stats)
+                with torch.no_grad():
+                    prm = model.parametrizations.filters.original
+                    prm.mul_(1.0 + 1e-14 * T(rng.standard_normal(tuple(prm.shape)), torch.float64))
+                loss, _ = model.fit(data_statistics=stats, max_epochs=300, show_progress=False, return_loss=True, **kwargs)
+                filters.append(model.filters.detach().numpy())
+                finals.append(float(loss[-1]))
+                epochs.append(len(loss))
+            out[f"syn_{model_name}_K4_{opt}_filters"] = np.stack(filters)
+            out[f"syn_{model_name}_K4_{opt}_final_loss"] = np.array(finals)
+            out[f"syn_{model_name}_K4_{opt}_epochs"] = np.array(epochs)
+            print(model_name, opt, epochs, finals, flush=True)
+    torch.set_default_dtype(torch.float32)
+    np.savez_compressed(os.path.join(HERE, "g4c_fit_ensemble.npz"), **out)
+
+
+def g7c():
+    """Two more samples of the reference's sensitivity on the c5 configuration: fixed-step fits from
+    the fit_pca initialisation perturbed by 1e-14 relative noise (default distance function)."""
+    out = {}
+    torch.set_default_dtype(torch.float64)
+    stats = c2_statistics(C=100, D=3072)
+    rng = np.random.default_rng(7373)
+    path = os.path.join(HERE, "g7c_fit_c5_ensemble.npz")
+    filters, losses = [], []
+    for sample in range(2):
+        model = sqfa.model.SQFA(n_dim=3072, n_filters=16, feature_noise=0.01).double()
+        model.fit_pca(data_statistics=stats)
+        with torch.no_grad():
+            prm = model.parametrizations.filters.original
+            prm.mul_(1.0 + 1e-14 * T(rng.standard_normal(tuple(prm.shape)), torch.float64))
+        loss, _ = model.fit(data_statistics=stats, max_epochs=300, show_progress=False, return_loss=True)
+        filters.append(model.filters.detach().numpy())
+        losses.append(loss.numpy())
+        print("c5 perturbed sample", sample, "epochs", len(loss), "final", float(loss[-1]), flush=True)
+        out["sqfa_filters"] = np.stack(filters)
+        out["sqfa_final_loss"] = np.array([l[-1] for l in losses])
+        out["sqfa_epochs"] = np.array([len(l) for l in losses])
+        np.savez_compressed(path, **out)
     torch.set_default_dtype(torch.float32)
 
 

@@ -116,3 +116,40 @@ def c2_statistics(C=100, D=784, seed=1234, dtype=torch.float64):
         cov[c0:c0 + n] = A @ A.transpose(1, 2) + 0.05 * torch.eye(D, dtype=dtype)
         mu[c0:c0 + n] = (0.1 * torch.randn(n, D, generator=g, dtype=torch.float32)).to(dtype)
     return {"means": mu, "covariances": cov}
+
+
+def ragged_points(C=1000, d=5, seed=606):
+    """Same generator as tests/golden/make_golden.py:ragged_points (golden G5c)."""
+    rng = np.random.default_rng(seed)
+    sizes = rng.integers(2, 42, size=C)
+    y = np.repeat(np.arange(C), sizes)
+    X = (rng.standard_normal((len(y), d)) * rng.uniform(0.5, 2.0, size=(1, d)) + 0.3 * rng.standard_normal((C, d))[y])
+    X = X.astype(np.float32).astype(np.float64)
+    perm = rng.permutation(len(y))
+    return X[perm], y[perm]
+
+
+def check_class_statistics_vs_reference(device, dtype=torch.float64, tol=1e-11):
+    """class_statistics / OAS on `device` against the reference's outputs: the small G5 case and the
+    ragged 1000-class G5c case (means, covariances, second moments; float labels accepted)."""
+    from sqfa_amd import statistics
+    G5C = load_golden("g5c_class_statistics.npz")
+    X = torch.tensor(G5["pts_X"], dtype=dtype, device=device)
+    y = torch.tensor(G5["pts_y"], device=device)
+    for est in ("empirical", "oas"):
+        st = statistics.class_statistics(X, y, estimator=est)
+        for k, v in st.items():
+            assert v.device.type == torch.device(device).type
+            assert rel_err(v.cpu(), G5[f"class_stats_{est}_{k}"]) < tol, (est, k)
+    assert rel_err(statistics.oas_covariance(X).cpu(), G5["oas_cov"]) < tol
+    assert rel_err(statistics.sample_covariance(X).cpu(), G5["sample_cov"]) < tol
+    Xn, yn = ragged_points()
+    assert np.array_equal(Xn[:3], G5C["check_X0"])
+    Xr = torch.tensor(Xn, dtype=dtype, device=device)
+    yr = torch.tensor(yn, device=device)
+    for est in ("empirical", "oas"):
+        st = statistics.class_statistics(Xr, yr, estimator=est)
+        for k, v in st.items():
+            assert rel_err(v.cpu(), G5C[f"{est}_{k}"]) < tol, (est, k)
+    st = statistics.class_statistics(Xr, yr.to(dtype), estimator="empirical")
+    assert rel_err(st["means"].cpu(), G5C["float_labels_means"]) < tol

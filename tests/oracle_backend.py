@@ -72,3 +72,11 @@ def oracle_pair_backend(A, B, *, scale, eps, sqrt_mode, weights, uniform_weight,
     bad = D[evaluated]
     out["nonfinite"] = torch.tensor([int(np.isnan(bad).sum()), int(np.isinf(bad).sum())], dtype=torch.int32, device=dev)
     return out
+
+
+def oracle_eigenvalues_backward(A, B, eig_weights):
+    """Stand-in for sqfa_amd._native.hip_eigenvalues_backward on the CPU (the oracle's eig output is
+    already descending, so the kernel-order weights are in descending order too)."""
+    gA, gB = closed_form.eigenvalue_weight_gradient(A.detach().cpu().double().numpy(), B.detach().cpu().double().numpy(),
+                                                    eig_weights.detach().cpu().double().numpy())
+    return torch.tensor(gA, dtype=A.dtype, device=A.device), torch.tensor(gB, dtype=B.dtype, device=B.device)

@@ -16,10 +16,13 @@ def test_closure_f64(key):
     mc.check_closure(key, torch.float64, DEV, tol_loss=1e-10, tol_grad=1e-7, tol_dist=1e-9)
 
 
-@pytest.mark.parametrize("key", [k for k in mc.G3_KEYS if "_n0_" not in k])
+@pytest.mark.parametrize("key", mc.G3_KEYS)
 def test_closure_f32(key):
-    # float32 against the float64 reference values; north_star: 1e-5 relative on the loss
-    mc.check_closure(key, torch.float32, DEV, tol_loss=1e-5, tol_grad=2e-3, tol_dist=2e-5)
+    """float32 closure against the float64 reference values.  north_star: 1e-5 relative on the loss;
+    the gradient bound is tied to the reference's OWN float32-vs-float64 deviation on the same
+    closure (golden G3 holds both): max(3e-5, 5 x that deviation), as in test_gpu_parity._tols."""
+    ref_dev = rel_err(mc.G3[f"{key}_grad_f32"], mc.G3[f"{key}_grad_f64"])
+    mc.check_closure(key, torch.float32, DEV, tol_loss=1e-5, tol_grad=max(3e-5, 5 * ref_dev), tol_dist=2e-5)
 
 
 @pytest.mark.parametrize("dname", ["rot", "syn"])
@@ -40,36 +43,103 @@ def test_full_fit_filters_match_reference_f64(dname, model_name, K, noise):
     mc.check_fit(dname, model_name, K, noise, 300, DEV, tol_loss=1e-6, tol_filters=1e-5)
 
 
+def _reference_drift(golden_b, key_a, golden_a, key_b):
+    """Relative distance between two fits of the REFERENCE itself that differ only by rounding:
+    its eigh-whitened distance (golden_a) vs the mathematically identical Cholesky-route
+    distance_fun plugged into the reference's own model (golden_b; make_golden.py:g4b/g7b)."""
+    return rel_err(golden_b[key_b], golden_a[key_a])
+
+
+def _ensemble_spread(model_name, opt, reference_filters):
+    """Largest distance from `reference_filters` among the reference's own fits started from 8 copies
+    of the same initialisation perturbed by 1e-14 relative noise (golden G4c, make_golden.py:g4c):
+    3e-4 ... 3.4e-3 with the fixed step, up to 5e-2 with strong_wolfe.  The optimum of the K=4
+    fits is nearly flat, so this -- not 1e-5 -- is what "the same filters" can mean here."""
+    from conftest import load_golden
+    G4C = load_golden("g4c_fit_ensemble.npz")
+    return max(rel_err(f, reference_filters) for f in G4C[f"syn_{model_name}_K4_{opt}_filters"])
+
+
 @pytest.mark.parametrize("model_name", ["smsqfa", "sqfa"])
 def test_full_fit_flat_orbit_case_f64(model_name):
-    """K=4 on the synthetic set converges along the nearly flat orbit F -> G F of the AIRM loss:
-    a 1e-15 relative difference in the gradient (closed form vs the reference's autograd) is
-    amplified by LBFGS to ~1e-3 in the filters even on the CPU with the float64 oracle
-    (tests/test_host_logic.py uses the same case), while the converged loss agrees.  So here the
-    criterion is the final loss (1e-5 relative) and a loose bound on the filters."""
+    """K=4 on the synthetic set converges along the nearly flat orbit F -> G F of the AIRM loss.
+    How well-posed "filters to 1e-5" is here is MEASURED on the reference: golden G4b holds the
+    reference's own fit with its distance_fun swapped for the same function evaluated through a
+    Cholesky whitening (rounding-level difference per evaluation) -- the reference then drifts from
+    itself by 6e-4 (smSQFA) / 7e-4 (SQFA) in the learned filters -- and golden G4c an ensemble of
+    reference fits from 1e-14-perturbed initialisations (spread up to 1.9e-3 / 3.4e-3).  The GPU fit
+    must stay within 2x the largest of those reference-vs-reference distances, match the converged
+    loss to 1e-5 and the epoch count to +-6."""
+    from conftest import load_golden
+    G4B = load_golden("g4b_fit_wellposed.npz")
     stats = mc.fit_stats("syn", torch.float64, DEV)
     model = mc.make_model(model_name, 50, 4, 1e-2, "sphere", torch.float64, DEV)
     model.fit_pca(data_statistics=stats)
     loss, _ = model.fit(data_statistics=stats, max_epochs=300, show_progress=False, return_loss=True)
     key = f"syn_{model_name}_K4_e300"
     ref = mc.G4[f"{key}_loss"]
+    drift = _reference_drift(G4B, f"{key}_filters", mc.G4, f"syn_{model_name}_K4_cholroute_filters")
+    F = model.filters.detach().cpu()
+    err = min(rel_err(F, mc.G4[f"{key}_filters"]), rel_err(F, G4B[f"syn_{model_name}_K4_cholroute_filters"]))
+    spread = max(drift, _ensemble_spread(model_name, "fixed", mc.G4[f"{key}_filters"]))
+    print(f"flat orbit {model_name}: GPU vs reference {err:.2e}; reference vs reference: Cholesky route {drift:.2e}, "
+          f"perturbed-init ensemble max {spread:.2e}")
     assert abs(loss[-1].item() - ref[-1]) <= 1e-5 * abs(ref[-1])
     assert abs(len(loss) - len(ref)) <= 6
-    assert rel_err(model.filters.detach().cpu(), mc.G4[f"{key}_filters"]) <= 5e-3
+    assert err <= 2 * spread
 
 
 @pytest.mark.parametrize("model_name", ["smsqfa", "sqfa"])
 def test_pairwise_fit_f64(model_name):
+    """Pairwise (two filters at a time) training is well-posed: the reference drifts from itself by
+    7e-11 (smSQFA) / 1.7e-6 (SQFA) under the Cholesky-route swap (golden G4b), so here the
+    north_star criterion applies as stated: learned filters to 1e-5."""
+    from conftest import load_golden
+    G4B = load_golden("g4b_fit_wellposed.npz")
     stats = mc.fit_stats("syn", torch.float64, DEV)
     model = mc.make_model(model_name, 50, 4, 1e-2, "sphere", torch.float64, DEV)
     model.fit_pca(data_statistics=stats)
     loss, t = model.fit(data_statistics=stats, max_epochs=300, show_progress=False, return_loss=True, pairwise=True)
     key = f"syn_{model_name}_pairwise_K4"
     ref = mc.G4[f"{key}_loss"]
+    drift = _reference_drift(G4B, f"{key}_filters", mc.G4, f"{key}_cholroute_filters")
+    err = rel_err(model.filters.detach().cpu(), mc.G4[f"{key}_filters"])
+    print(f"pairwise {model_name}: GPU vs reference {err:.2e}; reference vs reference (Cholesky route) {drift:.2e}")
     assert t.shape == loss.shape and (t[1:] >= t[:-1]).all()
-    assert abs(loss[-1].item() - ref[-1]) <= 1e-5 * abs(ref[-1])
-    assert rel_err(model.filters.detach().cpu(), mc.G4[f"{key}_filters"]) <= 5e-3
+    assert len(loss) == len(ref)
+    assert abs(loss[-1].item() - ref[-1]) <= 1e-6 * abs(ref[-1])
+    assert err <= max(1e-5, 4 * drift)
     assert model.noise_mat.shape == (4, 4) and model.filters.shape == (4, 50)
+
+
+@pytest.mark.parametrize("pairwise", [False, True])
+@pytest.mark.parametrize("model_name", ["smsqfa", "sqfa"])
+def test_strong_wolfe_fit_f64(model_name, pairwise):
+    """LBFGS keyword arguments are forwarded (reference src/sqfa/_optim.py:78-82):
+    line_search_fn="strong_wolfe" against the reference's own strong-Wolfe fits (golden G4b).  The line
+    search does not make the K=4 optimum well-posed either (the reference drifts from itself by
+    8e-4 / 4.7e-3 under the Cholesky-route swap and by up to 5e-2 over the perturbed-init ensemble of
+    golden G4c), so the bound is again 2x the reference's own largest drift; pairwise training is
+    well-posed (1e-8 / 3e-4) and gets max(1e-5, 4x its drift)."""
+    from conftest import load_golden
+    G4B = load_golden("g4b_fit_wellposed.npz")
+    tag = "pairwise_K4" if pairwise else "K4"
+    stats = mc.fit_stats("syn", torch.float64, DEV)
+    model = mc.make_model(model_name, 50, 4, 1e-2, "sphere", torch.float64, DEV)
+    model.fit_pca(data_statistics=stats)
+    loss, _ = model.fit(data_statistics=stats, max_epochs=300, show_progress=False, return_loss=True,
+                        pairwise=pairwise, line_search_fn="strong_wolfe")
+    key = f"syn_{model_name}_{tag}_wolfe"
+    ref = G4B[f"{key}_loss"]
+    drift = rel_err(G4B[f"{key}_cholroute_filters"], G4B[f"{key}_filters"])
+    F = model.filters.detach().cpu()
+    err = min(rel_err(F, G4B[f"{key}_filters"]), rel_err(F, G4B[f"{key}_cholroute_filters"]))
+    bound = max(1e-5, 4 * drift) if pairwise else 2 * max(drift, _ensemble_spread(model_name, "wolfe", G4B[f"{key}_filters"]))
+    print(f"strong_wolfe {model_name} {tag}: GPU vs reference {err:.2e}; reference vs reference (Cholesky route) {drift:.2e}; "
+          f"bound {bound:.2e}; epochs {len(loss)} vs {len(ref)}")
+    assert abs(loss[-1].item() - ref[-1]) <= 1e-5 * abs(ref[-1])
+    assert abs(len(loss) - len(ref)) <= 3
+    assert err <= bound
 
 
 @pytest.mark.parametrize("model_name", ["smsqfa", "sqfa"])
@@ -132,13 +202,23 @@ def test_c2_config_full_fit_matches_reference_f64(model_name):
 
 
 def test_c5_config_full_fit_matches_reference_f64():
-    """BASELINE config c5 shape (CIFAR-100-shaped: C=100, n_dim=3072, n_filters=16, SQFA):
-    full float64 fit on the GPU against the reference's float64 CPU fit (golden G7)."""
+    """BASELINE config c5 shape (CIFAR-100-shaped: C=100, n_dim=3072, n_filters=16, SQFA): full
+    float64 fit on the GPU against the reference's float64 CPU fit (golden G7).
+
+    north_star asks for "filters vs reference to 1e-5".  Golden G7b measures how well-posed that is on
+    this configuration with the reference alone: the SAME reference model with its distance_fun
+    swapped for the identical function evaluated through a Cholesky whitening (a 1e-15 relative
+    difference per evaluation) ends 2.2e-3 away from the reference's own filters (final losses 4.7e-4
+    apart, same 13 epochs; per-epoch losses agree to 1e-9 for five epochs, then separate).  The
+    fixed-step LBFGS trajectory is chaotic at K=16, for the reference itself.  Criteria: same epoch
+    count, first epochs to 1e-6, and filters AND final loss within 2x the reference-vs-reference
+    drift of the nearer of the two reference runs."""
     import os
     from conftest import GOLDEN_DIR, load_golden
     if not os.path.exists(os.path.join(GOLDEN_DIR, "g7_fit_c5.npz")):
         pytest.skip("g7_fit_c5.npz not generated")
     G7 = load_golden("g7_fit_c5.npz")
+    G7B = load_golden("g7b_fit_c5_wellposed.npz")
     stats = mc.c2_statistics(C=100, D=3072)
     assert np.allclose(stats["covariances"][0, :4, :4].numpy(), G7["check_cov00"], rtol=1e-12)
     stats = {k: v.to(DEV) for k, v in stats.items()}
@@ -146,19 +226,44 @@ def test_c5_config_full_fit_matches_reference_f64():
     model.fit_pca(data_statistics=stats)
     assert rel_err(model.filters.detach().cpu(), G7["sqfa_init"]) < 1e-8
     loss, t = model.fit(data_statistics=stats, max_epochs=300, show_progress=False, return_loss=True)
-    ref = G7["sqfa_loss"]
-    err = rel_err(model.filters.detach().cpu(), G7["sqfa_filters"])
+    ref, ref_b = G7["sqfa_loss"], G7B["sqfa_cholroute_loss"]
+    drift = rel_err(G7B["sqfa_cholroute_filters"], G7["sqfa_filters"])
+    drift_loss = abs(ref_b[-1] - ref[-1])
+    F = model.filters.detach().cpu()
+    err_a, err_b = rel_err(F, G7["sqfa_filters"]), rel_err(F, G7B["sqfa_cholroute_filters"])
     print(f"c5 sqfa: {len(loss)} epochs (reference {len(ref)}), GPU fit {t[-1].item():.2f} s vs reference CPU "
-          f"{float(G7['sqfa_seconds']):.1f} s, filters rel err {err:.2e}, final loss {loss[-1].item():.8f} vs {ref[-1]:.8f}")
+          f"{float(G7['sqfa_seconds']):.1f} s; filters vs reference {err_a:.2e}, vs reference/Cholesky-route {err_b:.2e}; "
+          f"reference vs reference {drift:.2e}; final loss {loss[-1].item():.8f} vs {ref[-1]:.8f} / {ref_b[-1]:.8f}")
     print("   per-epoch |loss - reference|:", np.abs(loss.numpy()[:len(ref)] - ref[:len(loss)]).round(8))
-    # With K=16 the reference's fixed-step LBFGS trajectory on this configuration is chaotic
-    # (its losses go -1.64, -3.11, -2.60, ... and settle at -1.86): rounding-level differences
-    # are amplified epoch by epoch, exactly like the flat-orbit case above.  Criteria: the
-    # first epochs agree tightly, the run stops after the same number of epochs, and the
-    # converged loss agrees to 1e-3.
-    assert len(loss) == len(ref)
+    assert len(loss) == len(ref) == len(ref_b)
     assert np.abs(loss.numpy()[:3] - ref[:3]).max() < 1e-6
-    assert abs(loss[-1].item() - ref[-1]) < 1e-3 * abs(ref[-1])
+    assert min(err_a, err_b) <= 2 * drift
+    assert min(abs(loss[-1].item() - ref[-1]), abs(loss[-1].item() - ref_b[-1])) <= 2 * drift_loss
+
+
+def test_c5_config_strong_wolfe_fit_f64():
+    """The same configuration with line_search_fn="strong_wolfe" (forwarded to LBFGS,
+    src/sqfa/_optim.py:78-82) against the reference's strong-Wolfe fits (golden G7b, both distance
+    routes): bound = max(1e-5, 2x the reference-vs-reference drift under that optimizer)."""
+    from conftest import load_golden
+    G7B = load_golden("g7b_fit_c5_wellposed.npz")
+    if "sqfa_wolfe_cholroute_filters" not in G7B:
+        pytest.skip("strong-Wolfe c5 goldens not generated")
+    stats = {k: v.to(DEV) for k, v in mc.c2_statistics(C=100, D=3072).items()}
+    model = mc.make_model("sqfa", 3072, 16, 0.01, "sphere", torch.float64, DEV)
+    model.fit_pca(data_statistics=stats)
+    loss, t = model.fit(data_statistics=stats, max_epochs=300, show_progress=False, return_loss=True,
+                        line_search_fn="strong_wolfe")
+    ref = G7B["sqfa_wolfe_loss"]
+    drift = rel_err(G7B["sqfa_wolfe_cholroute_filters"], G7B["sqfa_wolfe_filters"])
+    F = model.filters.detach().cpu()
+    err = min(rel_err(F, G7B["sqfa_wolfe_filters"]), rel_err(F, G7B["sqfa_wolfe_cholroute_filters"]))
+    print(f"c5 strong_wolfe: {len(loss)} epochs (reference {len(ref)}), {t[-1].item():.2f} s vs "
+          f"{float(G7B['sqfa_wolfe_seconds']):.0f} s; filters {err:.2e}; reference vs reference {drift:.2e}; "
+          f"final loss {loss[-1].item():.8f} vs {ref[-1]:.8f}")
+    assert abs(len(loss) - len(ref)) <= 2
+    assert np.abs(loss.numpy()[:3] - ref[:3]).max() < 1e-6
+    assert err <= max(1e-5, 2 * drift)
 
 
 @pytest.mark.parametrize("host_lbfgs", [True, False])
@@ -233,3 +338,10 @@ def test_device_side_compact_lbfgs_matches_torch_lbfgs(monkeypatch):
         runs[compact] = (loss.numpy(), model.filters.detach().cpu().numpy())
     assert np.abs(runs[True][0] - runs[False][0]).max() < 1e-9
     assert rel_err(runs[True][1], runs[False][1]) < 1e-7
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-11), (torch.float32, 2e-5)])
+def test_class_statistics_on_gpu_vs_reference(dtype, tol):
+    """SURVEY.md 8f rank 2 on the device: class_statistics / OAS (batched, device-resident) against
+    the reference's outputs -- the G5 case and a ragged 1000-class case (golden G5c)."""
+    mc.check_class_statistics_vs_reference(DEV, dtype, tol)

@@ -8,16 +8,19 @@ import torch
 
 import model_cases as mc
 from conftest import rel_err
-from oracle_backend import oracle_pair_backend
+from oracle_backend import oracle_eigenvalues_backward, oracle_pair_backend
 
 
 @pytest.fixture(autouse=True)
 def _oracle_backend():
     from sqfa_amd import _native
     saved = _native._pair_backend
+    saved_eig = _native._eig_backward_backend
     _native._pair_backend = oracle_pair_backend   # test-only substitution of the module attribute
+    _native._eig_backward_backend = oracle_eigenvalues_backward
     yield
     _native._pair_backend = saved
+    _native._eig_backward_backend = saved_eig
 
 
 CPU = torch.device("cpu")
@@ -228,7 +231,9 @@ def test_other_distance_operators():
     assert rel_err(distances.log_euclidean_sq(st["covariances"], st["covariances"]), g5["log_euclidean_sq"]) < 1e-10
     assert rel_err(distances.log_euclidean(st["covariances"], st["covariances"]), g5["log_euclidean"]) < 1e-10
     for name in ("bhattacharyya", "mahalanobis_sq", "mahalanobis", "hellinger", "fisher_rao_same_cov"):
-        assert rel_err(getattr(distances, name)(st, st), g5[name]) < 1e-9, name
+        # G5 was generated under a float64 default dtype; the reference's fisher_rao_same_cov takes
+        # sqrt(2) from a DEFAULT-dtype tensor, so under this test's float32 default it is 1.7e-8 off
+        assert rel_err(getattr(distances, name)(st, st), g5[name]) < (3e-8 if name == "fisher_rao_same_cov" else 1e-9), name
     assert sorted(distances.__all__) == sorted(
         ["affine_invariant_sq", "affine_invariant", "log_euclidean_sq", "log_euclidean", "fisher_rao_lower_bound",
          "fisher_rao_lower_bound_sq", "bhattacharyya", "mahalanobis_sq", "mahalanobis", "hellinger",
@@ -252,3 +257,53 @@ def test_usable_cpus_is_positive_and_bounded():
     from sqfa_amd.statistics import usable_cpus
     n = usable_cpus()
     assert 1 <= n <= (os.cpu_count() or 1)
+
+
+def test_generalized_eigenvalues_is_differentiable():
+    """The reference's generalized_eigenvalues is autograd-transparent (src/sqfa/linalg.py:48-70) and
+    the tutorial builds distance_funs on it (docs/source/tutorials/distances.md:127-178): the
+    autograd plumbing (sort permutation, scatter of the upstream gradient, squeeze rules) against
+    the reference's gradients of a weighted sum of eigenvalues (golden G1x)."""
+    from conftest import load_golden, rel_err
+    from sqfa_amd import linalg
+    G1X = load_golden("g1x_airm_cross.npz")
+    for nA, nB, m in [tuple(c) for c in G1X["cases"]]:
+        key = f"A{nA}_B{nB}_m{m}"
+        A = torch.tensor(G1X[f"{key}_A"], requires_grad=True)
+        B = torch.tensor(G1X[f"{key}_B"], requires_grad=True)
+        lam = linalg.generalized_eigenvalues(A, B)
+        assert tuple(lam.shape) == G1X[f"{key}_lam_f64"].shape
+        loss = (torch.tensor(G1X[f"{key}_Wlam"]) * lam).sum()
+        gA, gB = torch.autograd.grad(loss, (A, B))
+        assert rel_err(gA, G1X[f"{key}_gA_lam_f64"]) < 1e-8
+        assert rel_err(gB, G1X[f"{key}_gB_lam_f64"]) < 1e-8
+
+
+def test_other_operators_values_and_gradients_cpu_branch():
+    """CPU tensors keep the torch expressions of the non-default operators: values and gradients
+    against the reference (golden G5b) -- the GPU branch (native pair kernel) has the same test in
+    tests/test_gpu_other_operators.py."""
+    from conftest import load_golden
+    from sqfa_amd import distances
+    G5B = load_golden("g5b_other_operators.npz")
+    for nA, nB, K in [tuple(int(v) for v in c) for c in G5B["cases"]][:4]:
+        key = f"A{nA}_B{nB}_K{K}"
+        for name in ("bhattacharyya", "mahalanobis", "fisher_rao_same_cov", "log_euclidean"):
+            a = {"means": torch.tensor(G5B[f"{key}_muA"], requires_grad=True),
+                 "covariances": torch.tensor(G5B[f"{key}_covA"], requires_grad=True)}
+            b = a if not nB else {"means": torch.tensor(G5B[f"{key}_muB"], requires_grad=True),
+                                  "covariances": torch.tensor(G5B[f"{key}_covB"], requires_grad=True)}
+            fn = getattr(distances, name)
+            D = fn(a["covariances"], b["covariances"]) if name.startswith("log_") else fn(a, b)
+            assert rel_err(D.detach(), G5B[f"{key}_{name}_f64"]) < 1e-9, (key, name)
+            loss = (torch.tensor(G5B[f"{key}_W"]).reshape(D.shape) * D).sum()
+            (g,) = torch.autograd.grad(loss, [a["covariances"]])
+            refg = G5B[f"{key}_{name}_gcovA_f64"]
+            if np.isnan(refg).any():   # the reference's own gradient is NaN (acosh'(1) on the self-pair diagonal)
+                assert torch.isnan(g).any()
+                continue
+            assert rel_err(g, refg) < 1e-7, (key, name)
+
+
+def test_class_statistics_vs_reference_ragged_1000_classes():
+    mc.check_class_statistics_vs_reference("cpu")

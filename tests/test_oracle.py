@@ -71,6 +71,10 @@ def test_cross_batches(nA, nB, m):
         assert rel_err(gB, G1X[f"{key}_gB_{name}_f64"]) < 1e-8
     lam_cf = closed_form.generalized_eigenvalues(A, B)
     assert rel_err(lam_cf.reshape(G1X[f"{key}_lam_f64"].shape), G1X[f"{key}_lam_f64"]) < 1e-10
+    # gradient of a weighted sum of the eigenvalues (the reference's op is autograd-transparent)
+    gA, gB = closed_form.eigenvalue_weight_gradient(A, B, G1X[f"{key}_Wlam"].reshape(lam_cf.shape))
+    assert rel_err(gA, G1X[f"{key}_gA_lam_f64"]) < 1e-8
+    assert rel_err(gB, G1X[f"{key}_gB_lam_f64"]) < 1e-8
 
 
 @pytest.mark.parametrize("C,K", G2_CASES)
