@@ -356,10 +356,120 @@ __device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
   }
 }
 
+// The same round with the steps of one t processed TWO AT A TIME (they touch disjoint slots): both
+// partner columns are requested first (2 x MR cross-lane fetches back to back), then both inner
+// products / rotations are evaluated, then both second fetches, then both second updates.  In the
+// one-step-at-a-time form the compiler paces every inner product by the LDS crossbar (fetch, wait,
+// fma, five deep) and a wave spends a quarter of its time in s_waitcnt; with two steps in flight the
+// second step's fetch latency hides behind the first step's arithmetic.  Same rotations, same order
+// of the floating-point operations inside every step: results are bitwise identical.
+template <typename T, int MR, int CPL, int S, int SWZ, bool LONE_LAST, int C0, int C1, int T_>
+__device__ __forceinline__ void cross_step2(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], int s, T tol2, T tie, bool& big) {
+  using R = Real<T>;
+  constexpr int NS = (C1 >= 0) ? 2 : 1;
+  constexpr int cs[2] = {C0, C1 >= 0 ? C1 : C0};
+  constexpr int cps[2] = {C0 ^ T_, (C1 >= 0 ? C1 : C0) ^ T_};
+  T rv[2][MR];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+#pragma unroll
+    for (int r = 0; r < MR; ++r) rv[q][r] = lane_xor_row<S, SWZ>(x[cps[q]][r], s, r);  // partner's slot cp
+  }
+  T nr1[2], Dp[2];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    nr1[q] = lane_xor<S>(nrm[cps[q]], s);
+    Dp[q] = lane_xor<S>(D[cps[q]], s);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  T kgh[2], kg2[2], ru1[2];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    const int c = cs[q];
+    T gh = T(0);
+#pragma unroll
+    for (int r = 0; r < MR; ++r) gh = R::fma_(x[c][r], rv[q][r], gh);
+    T u1, k1, g21;
+    rot_scaled(nrm[c], nr1[q], gh, D[c], Dp[q], tol2, tie, u1, ru1[q], k1, g21, big);
+    kgh[q] = k1 * gh;
+    kg2[q] = k1 * g21;
+    const T a = -(kgh[q] * Dp[q]);
+#pragma unroll
+    for (int r = 0; r < MR; ++r) x[c][r] = R::fma_(a, rv[q][r], x[c][r]);
+    D[c] *= u1;
+    nrm[c] -= kg2[q];
+  }
+  if constexpr (T_ != 0) {
+    __builtin_amdgcn_sched_barrier(0);
+    // my slot cp meets the partner's slot c: the partner has just evaluated exactly that rotation
+    // from its side (as ITS slot-c rotation); its k is mine with the sign flipped.
+    T kgh2[2], kg22[2], ru2[2], Dpn[2];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      kgh2[q] = lane_xor<S>(kgh[q], s);
+      kg22[q] = lane_xor<S>(kg2[q], s);
+      ru2[q] = lane_xor<S>(ru1[q], s);
+      Dpn[q] = lane_xor<S>(D[cs[q]], s);  // partner's slot c, already rescaled
+#pragma unroll
+      for (int r = 0; r < MR; ++r) rv[q][r] = lane_xor_row<S, SWZ>(x[cs[q]][r], s, r);  // partner's slot c, rotated
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      const int cp = cps[q];
+      const T b = kgh2[q] * Dpn[q];
+#pragma unroll
+      for (int r = 0; r < MR; ++r) x[cp][r] = R::fma_(b, rv[q][r], x[cp][r]);
+      D[cp] *= ru2[q];
+      nrm[cp] += kg22[q];
+    }
+  }
+}
+
+// steps of round t: the slots c < (c ^ t) < CPL (t != 0) or all c (t == 0), two at a time
+template <typename T, int MR, int CPL, int S, int SWZ, bool LONE_LAST, int T_, int CSTART>
+__device__ __forceinline__ void cross_t_steps(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], int s, T tol2, T tie, bool& big) {
+  // find the next two valid first slots from CSTART on (compile time)
+  constexpr auto valid = [](int c) constexpr {
+    const int cp = c ^ T_;
+    if (c >= CPL || cp < c || cp >= CPL) return false;
+    if (LONE_LAST && c == CPL - 1 && cp == CPL - 1) return false;
+    return true;
+  };
+  constexpr int first = [&]() constexpr { int c = CSTART; while (c < CPL && !valid(c)) ++c; return c; }();
+  if constexpr (first < CPL) {
+    constexpr int second = [&]() constexpr { int c = first + 1; while (c < CPL && !valid(c)) ++c; return c; }();
+    if constexpr (second < CPL) {
+      cross_step2<T, MR, CPL, S, SWZ, LONE_LAST, first, second, T_>(x, nrm, D, s, tol2, tie, big);
+      cross_t_steps<T, MR, CPL, S, SWZ, LONE_LAST, T_, second + 1>(x, nrm, D, s, tol2, tie, big);
+    } else {
+      cross_step2<T, MR, CPL, S, SWZ, LONE_LAST, first, -1, T_>(x, nrm, D, s, tol2, tie, big);
+    }
+  }
+}
+
+template <typename T, int MR, int CPL, int S, int SWZ, bool LONE_LAST, int T_ = 0>
+__device__ __forceinline__ void cross_round_paired(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], int s, T tol2, bool& big) {
+  constexpr int TP2 = pow2ceil(CPL);
+  if constexpr (T_ < TP2) {
+    const int lane_id = (int)(threadIdx.x & 63);
+    const T tie = ((lane_id ^ s) > lane_id) ? T(1) : T(-1);
+    cross_t_steps<T, MR, CPL, S, SWZ, LONE_LAST, T_, 0>(x, nrm, D, s, tol2, tie, big);
+    cross_round_paired<T, MR, CPL, S, SWZ, LONE_LAST, T_ + 1>(x, nrm, D, s, tol2, big);
+  }
+}
+
+#ifndef SQFA_PAIRED_STEPS
+#define SQFA_PAIRED_STEPS 1  // 1: two steps in flight for float32 4-lane groups from MR = 16 on (measured: m=16 -1.8 %, m=17 -4.5 %, m=12 +1.5 %)
+#endif
+
 template <typename T, int MR, int G, int CPL, int S>
 __device__ __forceinline__ void cross_rounds_static(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], T tol2, bool& big) {
   if constexpr (S < G) {
-    cross_round<T, MR, CPL, S, swizzled_rows_of_8<T, G>(), (MR == G * (CPL - 1) + 1)>(x, nrm, D, S, tol2, big);
+    if constexpr (SQFA_PAIRED_STEPS && sizeof(T) == 4 && G == 4 && MR >= 16)
+      cross_round_paired<T, MR, CPL, S, swizzled_rows_of_8<T, G>(), (MR == G * (CPL - 1) + 1)>(x, nrm, D, S, tol2, big);
+    else
+      cross_round<T, MR, CPL, S, swizzled_rows_of_8<T, G>(), (MR == G * (CPL - 1) + 1)>(x, nrm, D, S, tol2, big);
     cross_rounds_static<T, MR, G, CPL, S + 1>(x, nrm, D, tol2, big);
   }
 }
@@ -805,6 +915,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
       //           them to this wave's private LDS accumulator of class i
       //   B side: over all 64 lanes (every pair of the wave shares j); lane l finishes entries
       //           idx = 64*i + l and stores them to the slab (this wave is the only writer)
+#ifndef SQFA_SKIP_OUTER   // development switch: upper bound of what moving the rank-one sums off the VALU could save
       {
         const int lo = lane;
         T* ga = s_ga + (size_t)(wave * TI + lo / G) * TRIP;
@@ -815,6 +926,18 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
         const OuterProduct<T, MR, CPL> prodB{x, coefB};
         tree_reduce_blocks<6, 0, (TRI + 63) / 64, TRI, T>(prodB, lo, [&](int idx, T v) { gb[idx] = v; });
       }
+#else
+      {  // keep u~ alive so that the back-transform is not optimised away
+        T* gb = static_cast<T*>(p.slab_grad) + ((size_t)tile * (TI + tj) + TI + jj) * TRI;
+        T acc = T(0);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+#pragma unroll
+          for (int r = 0; r < MR; ++r) acc += x[c][r] * (coefA[c] + coefB[c]);
+        }
+        if (lane < TRI) gb[lane] = acc;
+      }
+#endif
     }
   }
 
