@@ -152,6 +152,32 @@ int sqfa_feature_scatters_backward(const void *G, const void *T, int C, int D, i
                                    void *partial_out, void *stream);
 
 /*
+ * Closure glue: the same two products with the elementwise steps around them folded in, and the
+ * parametrization, so that one closure evaluation is 8 (SecondMomentsSQFA) / 11 (SQFA) launches.
+ *   sqfa_feature_scatters_ex        as sqfa_feature_scatters, plus `noise` added to the diagonal (the
+ *                                   feature_noise regulariser, src/sqfa/model.py:537-538) and, when means_f
+ *                                   (C,K) (the projected class means) is not NULL, the Calvo-Oller embedding
+ *                                   [[S + m m^T, m], [m^T, 1]] (src/sqfa/distances.py:141-174) written as
+ *                                   (C, K+1, K+1) into S_out
+ *   sqfa_feature_scatters_backward_ex  as sqfa_feature_scatters_backward for G stored with row pitch / class
+ *                                   size ldg (K, or K+1 to read the top-left block of a gradient wrt the embedding)
+ *   sqfa_embed_backward_means       gm_out (C,K) = (G + G^T) m + gE[:K,K] + gE[K,:K]: gradient wrt the projected means
+ *   sqfa_sphere_forward             F = X / ||X||_row, norms_out (K)    (Sphere.forward, src/sqfa/constraints.py:37)
+ *   sqfa_sphere_backward            grad_out (K,D) = gloss * (gF - F (F.gF)) / ||X||  with
+ *                                   gF = extra + sum_g partials[g]  (partials (n_groups,K,D) from the backward
+ *                                   product; extra (K,D) optional; gloss: device scalar or NULL = 1;
+ *                                   norms NULL = no constraint: grad_out = gloss * gF)
+ */
+int sqfa_feature_scatters_ex(const void *F, int K, int D, const void *T, int C, int dtype, double noise,
+                             const void *means_f, void *S_out, void *stream);
+int sqfa_feature_scatters_backward_ex(const void *G, int ldg, const void *T, int C, int D, int K, int dtype,
+                                      int n_groups, void *partial_out, void *stream);
+int sqfa_embed_backward_means(const void *gE, const void *means_f, int C, int K, int dtype, void *gm_out, void *stream);
+int sqfa_sphere_forward(const void *X, int K, int D, int dtype, void *F_out, void *norms_out, void *stream);
+int sqfa_sphere_backward(const void *X, const void *norms, int K, int D, int dtype, const void *partials, int n_groups,
+                         const void *extra, const void *gloss, void *grad_out, void *stream);
+
+/*
  * Per-pair Gaussian terms behind the reference's other distance_fun operators -- bhattacharyya
  * (src/sqfa/distances.py:240-280), mahalanobis[_sq] (:283-361), hellinger (:364-393),
  * fisher_rao_same_cov (:396-432) -- which all reduce to, with Sbar_ij = (Sigma_i + Sigma_j)/2 and

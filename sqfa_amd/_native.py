@@ -380,3 +380,131 @@ def project_scatters(scatters, filters):
     if native_projection_supported(scatters, filters):
         return ProjectScatters.apply(filters, scatters)
     return None
+
+
+# ------------------------------------------------------------------------------------------
+# the whole closure as one autograd node
+
+
+def fused_closure_supported(raw_filters, scatters, means):
+    """Conditions of the single-node closure: the streaming projection's (symmetric (C,D,D) scatters,
+    D % 4 == 0, K <= 64, 16-byte aligned), K % 4 == 0 for the backward product, float32/float64 on
+    the GPU; the means (SQFA) on the same device/dtype."""
+    K = raw_filters.shape[0]
+    if not (raw_filters.is_cuda and raw_filters.dim() == 2 and K % 4 == 0 and raw_filters.is_contiguous()):
+        return False
+    if means is not None and not (means.is_cuda and means.dtype == scatters.dtype and means.dim() == 2
+                                  and not means.requires_grad):
+        return False
+    return native_projection_supported(scatters, raw_filters)
+
+
+def closure_stage_forward(raw, scatters, means, noise, scale, sqrt_mode, weight, shard, sphere, fused=None):
+    """Kernels of one closure evaluation up to (and including) the pair kernels, no autograd:
+    sphere -> T = Psi F^T -> [m = mu F^T] -> S | E -> K0/K1/K2.  `fused` (S.numel() + 3 elements), when
+    given, receives [loss, nan, inf, dL/dS...] in place (the all-reduce buffer of a sharded evaluation).
+    Returns a dict with everything the backward stage needs."""
+    lib = _lib.load()
+    X = raw.detach().contiguous()
+    Psi = scatters.detach()
+    K, D = X.shape
+    C = Psi.shape[0]
+    code = _dtype_code(Psi)
+    dev, dt = Psi.device, Psi.dtype
+    with torch.cuda.device(dev):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        if sphere:
+            F = torch.empty_like(X)
+            norms = torch.empty(K, dtype=dt, device=dev)
+            _lib.check(lib.sqfa_sphere_forward(_ptr(X), K, D, code, _ptr(F), _ptr(norms), stream), "sqfa_sphere_forward")
+        else:
+            F, norms = X, None
+        T = torch.empty((C, D, K), dtype=dt, device=dev)
+        _lib.check(lib.sqfa_project_scatters(_ptr(F), K, D, _ptr(Psi), C, code, _ptr(T), stream), "sqfa_project_scatters")
+        if means is not None:
+            m = torch.matmul(means.detach(), F.t()).contiguous()       # (C,K) projected means
+            S = torch.empty((C, K + 1, K + 1), dtype=dt, device=dev)
+        else:
+            m = None
+            S = torch.empty((C, K, K), dtype=dt, device=dev)
+        _lib.check(lib.sqfa_feature_scatters_ex(_ptr(F), K, D, _ptr(T), C, code, float(noise), _ptr(m), _ptr(S), stream),
+                   "sqfa_feature_scatters_ex")
+    extra = {}
+    if fused is not None:
+        extra = {"out_loss": fused[0], "out_gradA": fused[3:].view(S.shape)}
+    out = _pair_backend(S, None, scale=scale, eps=EPSILON, sqrt_mode=sqrt_mode, weights=None,
+                        uniform_weight=weight, shard=shard, want_loss=True, want_grad=True,
+                        want_dist=False, want_eig=False, **extra)
+    if fused is not None:
+        fused[1:3].copy_(out["nonfinite"])   # int32 -> real in the copy itself
+    return {"X": X, "norms": norms, "T": T, "m": m, "means": means.detach() if means is not None else None,
+            "S_shape": tuple(S.shape), "loss": out["loss"], "nonfinite": out["nonfinite"], "gS": out["gradA"],
+            "sphere": sphere}
+
+
+def closure_stage_backward(st, gS, gloss):
+    """Kernels from dL/dS (or dL/dE) back to the raw filter parameter: backward product, [means path],
+    class reduction + sphere backward (+ multiplication by `gloss`, a device scalar or None)."""
+    lib = _lib.load()
+    X, norms, T, m, means = st["X"], st["norms"], st["T"], st["m"], st["means"]
+    C, D, K = T.shape
+    code = _dtype_code(T)
+    dev, dt = T.device, T.dtype
+    groups = min(FusedClosure.BACKWARD_GROUPS, C)
+    gS = gS.contiguous()
+    ldg = gS.shape[-1]
+    with torch.cuda.device(dev):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        partial = torch.empty((groups, K, D), dtype=dt, device=dev)
+        _lib.check(lib.sqfa_feature_scatters_backward_ex(_ptr(gS), ldg, _ptr(T), C, D, K, code, groups, _ptr(partial), stream),
+                   "sqfa_feature_scatters_backward_ex")
+        extra = None
+        if m is not None:
+            gm = torch.empty((C, K), dtype=dt, device=dev)
+            _lib.check(lib.sqfa_embed_backward_means(_ptr(gS), _ptr(m), C, K, code, _ptr(gm), stream), "sqfa_embed_backward_means")
+            extra = torch.matmul(gm.t(), means).contiguous()          # (K,D): m = mu F^T  =>  dL/dF += g_m^T mu
+        grad = torch.empty_like(X)
+        gl = gloss.detach().to(dt).contiguous() if gloss is not None else None
+        _lib.check(lib.sqfa_sphere_backward(_ptr(X), _ptr(norms if st["sphere"] else None), K, D, code, _ptr(partial), groups,
+                                            _ptr(extra), _ptr(gl), _ptr(grad), stream), "sqfa_sphere_backward")
+    return grad
+
+
+class FusedClosure(torch.autograd.Function):
+    """loss(raw filters) of one closure evaluation as ONE autograd node, 8 launches for
+    SecondMomentsSQFA and 11 for SQFA instead of ~40:
+
+        forward   sphere (or nothing)  ->  T = Psi F^T (streaming)  ->  [m = mu F^T]  ->
+                  S = F T + noise I  |  E = [[S + m m^T, m], [m^T, 1]]  ->  K0 / K1 / K2 (loss, dL/dS, flags)
+        backward  (G + G^T) T^T partial sums  ->  [g_m, g_m^T mu]  ->  class reduction + sphere backward + gloss
+
+    Same arithmetic as the chain Sphere -> ProjectScatters -> (+noise) -> embed_gaussian -> PairwiseLoss
+    it replaces (reference: src/sqfa/constraints.py:37, src/sqfa/model.py:172-188, 508-546,
+    src/sqfa/distances.py:141-174, src/sqfa/_optim.py:90-96); the summation order of the row norms
+    and of the class reduction differs (fixed, reproducible)."""
+
+    BACKWARD_GROUPS = 64
+
+    @staticmethod
+    def forward(ctx, raw, scatters, means, noise, scale, sqrt_mode, weight, shard, reducer, sphere):
+        fused = None
+        owner = getattr(reducer, "__self__", None)
+        if reducer is not None and shard[1] > 1 and _pair_backend is hip_pair_backend and hasattr(owner, "reduce_fused"):
+            C, K = scatters.shape[0], raw.shape[0]
+            m = K + 1 if means is not None else K
+            fused = torch.empty(C * m * m + 3, dtype=scatters.dtype, device=scatters.device)
+        st = closure_stage_forward(raw, scatters, means, noise, scale, sqrt_mode, weight, shard, sphere, fused)
+        loss, nonfinite, gS = st["loss"], st["nonfinite"], st["gS"]
+        if fused is not None:
+            loss, nonfinite, gS = owner.reduce_fused(fused, nonfinite, st["S_shape"])
+        elif reducer is not None:
+            loss, nonfinite, gS = reducer(loss, nonfinite, gS)
+        ctx.st = {k: v for k, v in st.items() if k not in ("loss", "nonfinite", "gS")}
+        ctx.gS = gS
+        ctx.mark_non_differentiable(nonfinite)
+        return loss, nonfinite
+
+    @staticmethod
+    def backward(ctx, gloss, _gflag):
+        grad = closure_stage_backward(ctx.st, ctx.gS, gloss)
+        return grad, None, None, None, None, None, None, None, None, None

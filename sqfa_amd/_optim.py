@@ -162,6 +162,87 @@ def fitting_loop(model, data_statistics, max_epochs=200, lr=0.1, atol=1e-6, show
             offset += n
         return host[0]
 
+    # ---- sharded fits (pair tiles over ranks): two captured graphs around the one collective --------
+    # stage A (parametrization -> projection -> pair kernels -> fused buffer [loss, nan, inf, dL/dS])
+    # and stage B (backward product -> class reduction + sphere backward -> packed [loss, nan, inf, grad])
+    # are captured once each; a closure is: replay A, ONE all-reduce of the fused buffer (eager: works for
+    # RCCL and gloo alike), replay B, ONE device-to-host copy.  Needs the single-node closure's conditions
+    # (model._single_node_inputs); other sharded fits stay eager.
+    split = {"state": "off", "calls": 0}
+    if (GRAPH_CLOSURE and len(device_params) == 1 and device_params[0].is_cuda
+            and getattr(model, "pair_shard", None) is not None and getattr(model, "class_shard", None) is None
+            and model.pair_shard.world_size > 1
+            and hasattr(model, "_has_fused_closure") and model._has_fused_closure()
+            and hasattr(model, "_single_node_inputs") and model._single_node_inputs(prepared) is not None
+            and model._noise_scalar() is not None):
+        split["state"] = "warmup"
+
+    def split_stages():
+        """(stage_a, stage_b) closures over static tensors, for eager warm-up and capture."""
+        from . import _native, distances
+        import torch.distributed as dist
+        raw, scatters, means, sphere = model._single_node_inputs(prepared)
+        _, scale, sqrt_mode = distances.fused_spec(model.distance_fun)
+        noise = model._noise_scalar()
+        C, K = scatters.shape[0], raw.shape[0]
+        m = K + 1 if means is not None else K
+        weight = -1.0 / (C * (C - 1) // 2)
+        shard = model.pair_shard
+        fused = torch.empty(C * m * m + 3, dtype=scatters.dtype, device=scatters.device)
+        box = {}
+
+        def stage_a():
+            box["st"] = _native.closure_stage_forward(raw, scatters, means, noise, scale, sqrt_mode, weight,
+                                                      shard.shard, sphere, fused)
+
+        def reduce():
+            dist.all_reduce(fused, op=dist.ReduceOp.SUM, group=shard.group)
+
+        def stage_b():
+            grad = _native.closure_stage_backward(box["st"], fused[3:].view(C, m, m), None)
+            box["grad"] = grad
+            box["packed"] = torch.cat([fused[:3], grad.reshape(-1)])
+
+        return stage_a, reduce, stage_b, box
+
+    def capture_split():
+        stage_a, reduce, stage_b, box = split["stages"]
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            stage_a()
+        reduce()
+        with torch.cuda.graph(gb, pool=ga.pool()):
+            stage_b()
+        split.update(ga=ga, gb=gb, state="on")
+
+    def split_closure():
+        push_parameters()
+        if split.get("stages") is None:
+            split["stages"] = split_stages()
+        stage_a, reduce, stage_b, box = split["stages"]
+        if split["state"] == "warmup" and split["calls"] >= GRAPH_WARMUP_CLOSURES:
+            try:
+                capture_split()
+            except Exception as err:
+                warnings.warn(f"sqfa_amd: HIP graph capture of the sharded closure failed ({err}); running eagerly")
+                split["state"] = "eager"
+        if split["state"] == "on":
+            split["ga"].replay()
+            reduce()
+            split["gb"].replay()
+        else:
+            split["calls"] += 1
+            stage_a()
+            reduce()
+            stage_b()
+        packed = box["packed"]
+        device_params[0].grad = box["grad"]
+        if use_host:
+            return unpack_to_host(packed)
+        head = packed[:3].cpu()
+        raise_on_flags(head[1:3].round().to(torch.int32))
+        return head[0]
+
     graph = {"state": "off", "calls": 0, "graph": None, "packed": None, "grads": None}
     if (GRAPH_CLOSURE and len(device_params) > 0 and all(p.is_cuda for p in device_params)
             and getattr(model, "pair_shard", None) is None and getattr(model, "class_shard", None) is None
@@ -178,6 +259,8 @@ def fitting_loop(model, data_statistics, max_epochs=200, lr=0.1, atol=1e-6, show
         graph.update(graph=g, packed=packed, grads=[p.grad for p in device_params], state="on")
 
     def closure():
+        if split["state"] != "off":
+            return split_closure()
         push_parameters()
         if graph["state"] == "warmup" and graph["calls"] >= GRAPH_WARMUP_CLOSURES:
             try:

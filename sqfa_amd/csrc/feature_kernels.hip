@@ -24,7 +24,8 @@ namespace sqfa {
 template <typename T, int NB, int SPLIT>
 __global__ __launch_bounds__(64 * NB * SPLIT) void feature_scatters_kernel(const T* __restrict__ F,
                                                                            const T* __restrict__ Tm,
-                                                                           T* __restrict__ S, int D, int K) {
+                                                                           T* __restrict__ S, int D, int K, T noise,
+                                                                           const T* __restrict__ means, int ld) {
   using Tr = ProjTraits<T>;
   using Acc = typename Tr::Acc;
   __shared__ T s_part[SPLIT][NB][NB][4][64];
@@ -55,7 +56,18 @@ __global__ __launch_bounds__(64 * NB * SPLIT) void feature_scatters_kernel(const
     for (int reg = 0; reg < 4; ++reg) s_part[part][w][nb][reg][lane] = acc[nb][reg];
   __syncthreads();
   if (part != 0) return;
-  T* out = S + (size_t)c * K * K;
+  // epilogue (fused closure glue): + noise * I (reference src/sqfa/model.py:537-538) and, when the
+  // projected means m_c (K) are given, the Calvo-Oller embedding [[S + m m^T, m], [m^T, 1]]
+  // (src/sqfa/distances.py:141-174) written with row pitch ld = K + 1
+  T* out = S + (size_t)c * ld * ld;
+  const T* mc = means != nullptr ? means + (size_t)c * K : nullptr;
+  if (mc != nullptr && w == 0) {
+    for (int a = lane; a < K; a += 64) {
+      out[(size_t)a * ld + K] = mc[a];
+      out[(size_t)K * ld + a] = mc[a];
+    }
+    if (lane == 0) out[(size_t)K * ld + K] = T(1);
+  }
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
@@ -64,7 +76,11 @@ __global__ __launch_bounds__(64 * NB * SPLIT) void feature_scatters_kernel(const
 #pragma unroll
       for (int p2 = 0; p2 < SPLIT; ++p2) v += s_part[p2][w][nb][reg][lane];  // fixed order
       const int a_row = 16 * w + Tr::acc_row(q, reg), b_col = 16 * nb + r16;
-      if (a_row < K && b_col < K) out[(size_t)a_row * K + b_col] = v;
+      if (a_row < K && b_col < K) {
+        if (a_row == b_col) v += noise;
+        if (mc != nullptr) v += mc[a_row] * mc[b_col];
+        out[(size_t)a_row * ld + b_col] = v;
+      }
     }
   }
 }
@@ -78,7 +94,8 @@ __global__ __launch_bounds__(64 * NB * SPLIT) void feature_scatters_kernel(const
 // caller: bitwise reproducible.
 template <typename T, int NB>
 __global__ __launch_bounds__(64) void feature_backward_kernel(const T* __restrict__ G, const T* __restrict__ Tm,
-                                                              T* __restrict__ P, int C, int D, int K, int n_groups) {
+                                                              T* __restrict__ P, int C, int D, int K, int n_groups,
+                                                              int ldg) {
   using Tr = ProjTraits<T>;
   using Acc = typename Tr::Acc;
   const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
@@ -91,7 +108,7 @@ __global__ __launch_bounds__(64) void feature_backward_kernel(const T* __restric
     for (int reg = 0; reg < 4; ++reg) acc[na][reg] = T(0);
   for (int c = g; c < C; c += n_groups) {
     const T* __restrict__ tc = Tm + ((size_t)c * D + (d_ok ? d : 0)) * K;
-    const T* __restrict__ gc = G + (size_t)c * K * K;
+    const T* __restrict__ gc = G + (size_t)c * ldg * ldg;  // (ldg, ldg) per class: K, or K + 1 for a gradient wrt the embedding
     // all loads of the class first (independent), then the MFMAs
     T tv[NB][4], sv[NB][NB][4];
 #pragma unroll
@@ -105,7 +122,7 @@ __global__ __launch_bounds__(64) void feature_backward_kernel(const T* __restric
         const bool ok = a < K && b0 < K;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          sv[bc][na][e] = ok ? gc[(size_t)a * K + b0 + e] + gc[(size_t)(b0 + e) * K + a] : T(0);
+          sv[bc][na][e] = ok ? gc[(size_t)a * ldg + b0 + e] + gc[(size_t)(b0 + e) * ldg + a] : T(0);
       }
     }
 #pragma unroll
@@ -127,23 +144,24 @@ __global__ __launch_bounds__(64) void feature_backward_kernel(const T* __restric
 }
 
 template <typename T>
-static void launch_forward(const T* f, const T* t, T* s, int C, int D, int K, hipStream_t stream) {
+static void launch_forward(const T* f, const T* t, T* s, int C, int D, int K, T noise, const T* means, int ld,
+                           hipStream_t stream) {
   switch ((K + 15) / 16) {
-    case 1: hipLaunchKernelGGL((feature_scatters_kernel<T, 1, 8>), dim3(C), dim3(512), 0, stream, f, t, s, D, K); break;
-    case 2: hipLaunchKernelGGL((feature_scatters_kernel<T, 2, 4>), dim3(C), dim3(512), 0, stream, f, t, s, D, K); break;
-    case 3: hipLaunchKernelGGL((feature_scatters_kernel<T, 3, 2>), dim3(C), dim3(384), 0, stream, f, t, s, D, K); break;
-    default: hipLaunchKernelGGL((feature_scatters_kernel<T, 4, 2>), dim3(C), dim3(512), 0, stream, f, t, s, D, K); break;
+    case 1: hipLaunchKernelGGL((feature_scatters_kernel<T, 1, 8>), dim3(C), dim3(512), 0, stream, f, t, s, D, K, noise, means, ld); break;
+    case 2: hipLaunchKernelGGL((feature_scatters_kernel<T, 2, 4>), dim3(C), dim3(512), 0, stream, f, t, s, D, K, noise, means, ld); break;
+    case 3: hipLaunchKernelGGL((feature_scatters_kernel<T, 3, 2>), dim3(C), dim3(384), 0, stream, f, t, s, D, K, noise, means, ld); break;
+    default: hipLaunchKernelGGL((feature_scatters_kernel<T, 4, 2>), dim3(C), dim3(512), 0, stream, f, t, s, D, K, noise, means, ld); break;
   }
 }
 
 template <typename T>
-static void launch_backward(const T* g, const T* t, T* p, int C, int D, int K, int n_groups, hipStream_t stream) {
+static void launch_backward(const T* g, const T* t, T* p, int C, int D, int K, int n_groups, int ldg, hipStream_t stream) {
   const dim3 grid((D + 15) / 16, n_groups, 1), block(64);
   switch ((K + 15) / 16) {
-    case 1: hipLaunchKernelGGL((feature_backward_kernel<T, 1>), grid, block, 0, stream, g, t, p, C, D, K, n_groups); break;
-    case 2: hipLaunchKernelGGL((feature_backward_kernel<T, 2>), grid, block, 0, stream, g, t, p, C, D, K, n_groups); break;
-    case 3: hipLaunchKernelGGL((feature_backward_kernel<T, 3>), grid, block, 0, stream, g, t, p, C, D, K, n_groups); break;
-    default: hipLaunchKernelGGL((feature_backward_kernel<T, 4>), grid, block, 0, stream, g, t, p, C, D, K, n_groups); break;
+    case 1: hipLaunchKernelGGL((feature_backward_kernel<T, 1>), grid, block, 0, stream, g, t, p, C, D, K, n_groups, ldg); break;
+    case 2: hipLaunchKernelGGL((feature_backward_kernel<T, 2>), grid, block, 0, stream, g, t, p, C, D, K, n_groups, ldg); break;
+    case 3: hipLaunchKernelGGL((feature_backward_kernel<T, 3>), grid, block, 0, stream, g, t, p, C, D, K, n_groups, ldg); break;
+    default: hipLaunchKernelGGL((feature_backward_kernel<T, 4>), grid, block, 0, stream, g, t, p, C, D, K, n_groups, ldg); break;
   }
 }
 
@@ -153,31 +171,44 @@ static bool shape_ok(int K, int D, int C, int dtype) {
 
 }  // namespace sqfa
 
-extern "C" int sqfa_feature_scatters(const void* F, int K, int D, const void* T, int C, int dtype, void* S_out,
-                                     void* stream_) {
+extern "C" int sqfa_feature_scatters_ex(const void* F, int K, int D, const void* T, int C, int dtype, double noise,
+                                        const void* means_f, void* S_out, void* stream_) {
   using namespace sqfa;
   if (F == nullptr || T == nullptr || S_out == nullptr || !shape_ok(K, D, C, dtype)) return SQFA_ERR_BAD_ARGUMENT;
   if ((D % 4) != 0 || K > 64) return SQFA_ERR_UNSUPPORTED_M;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int ld = means_f != nullptr ? K + 1 : K;
   if (dtype == SQFA_F32)
-    launch_forward(static_cast<const float*>(F), static_cast<const float*>(T), static_cast<float*>(S_out), C, D, K, stream);
+    launch_forward(static_cast<const float*>(F), static_cast<const float*>(T), static_cast<float*>(S_out), C, D, K,
+                   (float)noise, static_cast<const float*>(means_f), ld, stream);
   else
-    launch_forward(static_cast<const double*>(F), static_cast<const double*>(T), static_cast<double*>(S_out), C, D, K, stream);
+    launch_forward(static_cast<const double*>(F), static_cast<const double*>(T), static_cast<double*>(S_out), C, D, K,
+                   noise, static_cast<const double*>(means_f), ld, stream);
   return hipGetLastError() == hipSuccess ? SQFA_OK : SQFA_ERR_LAUNCH;
 }
 
-extern "C" int sqfa_feature_scatters_backward(const void* G, const void* T, int C, int D, int K, int dtype, int n_groups,
-                                              void* partial_out, void* stream_) {
+extern "C" int sqfa_feature_scatters(const void* F, int K, int D, const void* T, int C, int dtype, void* S_out,
+                                     void* stream_) {
+  return sqfa_feature_scatters_ex(F, K, D, T, C, dtype, 0.0, nullptr, S_out, stream_);
+}
+
+extern "C" int sqfa_feature_scatters_backward_ex(const void* G, int ldg, const void* T, int C, int D, int K, int dtype,
+                                                 int n_groups, void* partial_out, void* stream_) {
   using namespace sqfa;
-  if (G == nullptr || T == nullptr || partial_out == nullptr || !shape_ok(K, D, C, dtype) || n_groups < 1)
+  if (G == nullptr || T == nullptr || partial_out == nullptr || !shape_ok(K, D, C, dtype) || n_groups < 1 || ldg < K)
     return SQFA_ERR_BAD_ARGUMENT;
   if ((K % 4) != 0 || K > 64) return SQFA_ERR_UNSUPPORTED_M;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (dtype == SQFA_F32)
     launch_backward(static_cast<const float*>(G), static_cast<const float*>(T), static_cast<float*>(partial_out), C, D, K,
-                    n_groups, stream);
+                    n_groups, ldg, stream);
   else
     launch_backward(static_cast<const double*>(G), static_cast<const double*>(T), static_cast<double*>(partial_out), C, D,
-                    K, n_groups, stream);
+                    K, n_groups, ldg, stream);
   return hipGetLastError() == hipSuccess ? SQFA_OK : SQFA_ERR_LAUNCH;
+}
+
+extern "C" int sqfa_feature_scatters_backward(const void* G, const void* T, int C, int D, int K, int dtype, int n_groups,
+                                              void* partial_out, void* stream_) {
+  return sqfa_feature_scatters_backward_ex(G, K, T, C, D, K, dtype, n_groups, partial_out, stream_);
 }

@@ -129,3 +129,75 @@ def test_rccl_backend_single_rank():
     assert abs(loss - ref_l) < 1e-5 * abs(ref_l)
     assert np.linalg.norm(grad - G1["C37_m16_grad_f64"]) < 5e-5 * np.linalg.norm(G1["C37_m16_grad_f64"])
     assert np.abs(fl - G4["syn_sqfa_K2_e3_loss"]).max() < 1e-6
+
+
+def _split_graph_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import model_cases as mc
+        import sqfa_amd._optim as opt
+        from sqfa_amd.parallel import PairShard
+        dev = torch.device("cuda:0")
+        stats = {k: v.to(dev) for k, v in mc.c2_statistics(C=24, D=96).items()}
+        counts = {"replay": 0, "cpu": 0}
+        original_replay, original_cpu = torch.cuda.CUDAGraph.replay, torch.Tensor.cpu
+
+        def replay(self):
+            counts["replay"] += 1
+            return original_replay(self)
+
+        def cpu(self, *a, **k):
+            if self.is_cuda:
+                counts["cpu"] += 1
+            return original_cpu(self, *a, **k)
+
+        torch.cuda.CUDAGraph.replay = replay
+        torch.Tensor.cpu = cpu
+        runs = {}
+        for name, use_graph, sharded in (("eager", False, True), ("split", True, True), ("single", True, False)):
+            opt.GRAPH_CLOSURE = use_graph
+            model = mc.make_model("sqfa", 96, 4, 0.01, "sphere", torch.float64, dev)
+            model.fit_pca(data_statistics=stats)
+            if sharded:
+                model.pair_shard = PairShard()
+            counts["replay"] = counts["cpu"] = 0
+            loss, _ = model.fit(data_statistics=stats, max_epochs=6, show_progress=False, return_loss=True)
+            runs[name] = (loss.numpy(), original_cpu(model.filters.detach()).numpy(), dict(counts))
+        q.put((rank, runs))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sharded_closure_runs_as_two_graphs_around_one_all_reduce():
+    """the pair-sharded closure is captured as graph A (parametrization ->
+    projection -> pair kernels -> fused buffer) and graph B (backward -> packed result) with the single
+    all-reduce between them: identical filters to the eager sharded fit and to the single-process fit,
+    two replays and ONE device-to-host read per closure."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30300 + os.getpid() % 2000
+    procs = [ctx.Process(target=_split_graph_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=500) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, r0), (_, r1) = results
+    for name in ("eager", "split", "single"):
+        assert np.array_equal(r0[name][0], r1[name][0]) and np.array_equal(r0[name][1], r1[name][1])   # ranks agree bitwise
+    le, Fe, ce = r0["eager"]
+    ls, Fs, cs = r0["split"]
+    l1, F1, c1 = r0["single"]
+    assert ce["replay"] == 0
+    assert cs["replay"] > 40, "the split-graph path was not taken"
+    closures = cs["replay"] // 2 + 3                      # + the eager warm-up closures
+    assert cs["cpu"] <= closures + 2, (cs, closures)      # one read-back per closure
+    assert np.abs(ls - le).max() < 1e-12 and np.linalg.norm(Fs - Fe) < 1e-10 * np.linalg.norm(Fe)
+    assert np.abs(ls - l1).max() < 1e-9 and np.linalg.norm(Fs - F1) < 1e-8 * np.linalg.norm(F1)

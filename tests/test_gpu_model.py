@@ -345,3 +345,31 @@ def test_class_statistics_on_gpu_vs_reference(dtype, tol):
     """SURVEY.md 8f rank 2 on the device: class_statistics / OAS (batched, device-resident) against
     the reference's outputs -- the G5 case and a ragged 1000-class case (golden G5c)."""
     mc.check_class_statistics_vs_reference(DEV, dtype, tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("constraint", ["sphere", "none"])
+@pytest.mark.parametrize("model_name,C,D,K", [("smsqfa", 24, 96, 4), ("sqfa", 24, 96, 4), ("sqfa", 300, 64, 16),
+                                              ("smsqfa", 7, 132, 32), ("sqfa", 5, 40, 8)])
+def test_single_node_closure_matches_autograd_chain(model_name, C, D, K, constraint, dtype):
+    """_native.FusedClosure (sphere -> projection -> noise/embedding -> pair loss as ONE autograd node,
+    8 / 11 launches) against the chain of autograd nodes it replaces: same loss, flags and gradient
+    with respect to the raw filter parameter."""
+    import sqfa_amd
+    stats = {k: v.to(dtype).to(DEV) for k, v in mc.c2_statistics(C=C, D=D).items()}
+    inp = stats if model_name == "sqfa" else stats["covariances"] + stats["means"][:, :, None] * stats["means"][:, None, :]
+    model = mc.make_model(model_name, D, K, 0.01, constraint, dtype, DEV)
+    prepared = model._prepare_statistics(inp)
+    results = []
+    for single in (True, False):
+        model.SINGLE_NODE_CLOSURE = single
+        assert (model._single_node_inputs(prepared) is not None) == single
+        model.zero_grad()
+        loss, flags = model._fused_closure_loss(prepared)
+        (3.0 * loss).backward()                      # a non-unit incoming gradient
+        results.append((loss.item(), flags.tolist(), model.parametrizations.filters.original.grad.clone()))
+    (l1, f1, g1), (l0, f0, g0) = results
+    assert f1 == f0 == [0, 0]
+    tol = 1e-12 if dtype == torch.float64 else 2e-6
+    assert abs(l1 - l0) <= tol * abs(l0)
+    assert rel_err(g1.cpu(), g0.cpu()) <= (1e-10 if dtype == torch.float64 else 2e-4)
