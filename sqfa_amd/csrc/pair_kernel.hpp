@@ -459,14 +459,25 @@ __device__ __forceinline__ void cross_round_paired(T (&x)[CPL][MR], T (&nrm)[CPL
   }
 }
 
+// Two steps in flight (cross_step2) where it was measured to pay (C=1000, MI355X): float32 4-lane
+// groups from MR = 16 on (m=16 -1.8 %, m=17 -4.5 %; m=12 +1.5 %: off) and float32 8-lane groups
+// (m=24 -3.5 %, m=32 -6 %, m=33 -7.6 %: two waves per SIMD hide less latency by themselves).
 #ifndef SQFA_PAIRED_STEPS
-#define SQFA_PAIRED_STEPS 1  // 1: two steps in flight for float32 4-lane groups from MR = 16 on (measured: m=16 -1.8 %, m=17 -4.5 %, m=12 +1.5 %)
+#define SQFA_PAIRED_STEPS 1
 #endif
+#ifndef SQFA_PAIRED_F64
+#define SQFA_PAIRED_F64 1  // float64: m=12 -3.5 %, m=17 -3 %, m=8 / m=16 unchanged
+#endif
+template <typename T, int G, int MR> constexpr bool paired_steps() {
+  if (!SQFA_PAIRED_STEPS) return false;
+  if (sizeof(T) == 8) return SQFA_PAIRED_F64 != 0;
+  return (G == 4 && MR >= 16) || G == 8;
+}
 
 template <typename T, int MR, int G, int CPL, int S>
 __device__ __forceinline__ void cross_rounds_static(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], T tol2, bool& big) {
   if constexpr (S < G) {
-    if constexpr (SQFA_PAIRED_STEPS && sizeof(T) == 4 && G == 4 && MR >= 16)
+    if constexpr (paired_steps<T, G, MR>())
       cross_round_paired<T, MR, CPL, S, swizzled_rows_of_8<T, G>(), (MR == G * (CPL - 1) + 1)>(x, nrm, D, S, tol2, big);
     else
       cross_round<T, MR, CPL, S, swizzled_rows_of_8<T, G>(), (MR == G * (CPL - 1) + 1)>(x, nrm, D, S, tol2, big);
