@@ -32,6 +32,7 @@ if ROOT not in sys.path:
 
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector == f32 MFMA dense peak
 HBM_PEAK_GBS = 8000.0
+PMC_FILE = "r2_pmc_c3.json"   # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary the `traffic` fields quote
 
 WORKLOADS = {
     # name: (C, D, K, model)   model: "smsqfa" -> m=K, "sqfa" -> m=K+1 (Calvo-Oller embedding, scale 1/2)
@@ -185,7 +186,7 @@ def pmc_traffic(kernel, workload, dtype):
     """HBM bytes per launch from the committed rocprofv3 --pmc summary (collected in separate
     FETCH_SIZE / WRITE_SIZE passes as MI355X_MICROARCH.md prescribes; see the file's `correction`).
     Only quoted for the workload it was measured on."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_c3.json")
+    path = os.path.join(ROOT, "profiles", PMC_FILE)
     if workload != "c3" or dtype != "f32" or not os.path.exists(path):
         return None
     with open(path) as fh:
@@ -420,7 +421,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved_tf / FP32_PEAK_TFLOPS,
                 "traffic": pmc_traffic("pair_tile_kernel", args.workload, args.dtype) if world == 1 else None,
-                "traffic_unit": "bytes per launch (profiles/r1_pmc_c3.json)",
+                "traffic_unit": f"bytes per launch (profiles/{PMC_FILE})",
                 "kernel": "pair_tile_kernel",
                 "kernel_ms": kernel_ms,
                 "algorithmic_flops_per_launch": flops_launch,
@@ -437,7 +438,7 @@ def main():
             torch.cuda.empty_cache()
             result["closure"] = closure_benchmark(C, D, K, model, device, max(10, min(100, args.steps // 2)), lib, with_fit=args.fit)
             result["closure"]["roofline"]["traffic"] = pmc_traffic("project_kernel", args.workload, args.dtype)
-            result["closure"]["roofline"]["traffic_unit"] = "bytes per launch (profiles/r1_pmc_c3.json)"
+            result["closure"]["roofline"]["traffic_unit"] = f"bytes per launch (profiles/{PMC_FILE})"
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(S_cpu, scale, C)
             result["speedup_vs_cpu_baseline"] = evals_per_s / result["cpu_baseline"]["value"]

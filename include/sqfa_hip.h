@@ -61,8 +61,11 @@ const char *sqfa_hip_last_error(void); /* text of the last HIP error seen by thi
 int sqfa_airm_tiling(int nA, int nB, int m, int dtype,
                      int *tile_i, int *tile_j, int *n_tiles_i, int *n_tiles_j, int *padded_m);
 
-/* Bytes of device workspace sqfa_airm_pairwise needs for this problem (0 on error). */
+/* Bytes of device workspace sqfa_airm_pairwise needs for this problem with ANY shard_count (0 on error). */
 size_t sqfa_airm_workspace_bytes(int nA, int nB, int m, int dtype);
+/* The same for calls with this shard_count only (the tile width, hence the slab, depends on it):
+ * at C=1000, m=16 103 MB for shard_count 1 instead of the 171 MB bound above. */
+size_t sqfa_airm_workspace_bytes_sharded(int nA, int nB, int m, int dtype, int shard_count);
 
 /*
  * Pairwise affine-invariant distances between two batches of SPD matrices, the

@@ -27,6 +27,7 @@ PROTOTYPES = {
     "sqfa_hip_last_error": (ctypes.c_char_p, []),
     "sqfa_airm_tiling": (ctypes.c_int, [ctypes.c_int] * 4 + [_c_int_p] * 5),
     "sqfa_airm_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),
+    "sqfa_airm_workspace_bytes_sharded": (ctypes.c_size_t, [ctypes.c_int] * 5),
     "sqfa_airm_pairwise": (
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -56,7 +56,7 @@ def hip_pair_backend(A, B, *, scale, eps, sqrt_mode, weights, uniform_weight, sh
         raise NotImplementedError(
             f"matrix size {m} exceeds the largest size the native kernels handle ({lib.sqfa_hip_max_dim()})"
         )
-    nbytes = lib.sqfa_airm_workspace_bytes(nA, nB, m, code)
+    nbytes = lib.sqfa_airm_workspace_bytes_sharded(nA, nB, m, code, int(shard[1]))
     if nbytes == 0:
         raise _lib.NativeLibraryError("sqfa_airm_workspace_bytes rejected the problem shape")
     dev = A.device

@@ -63,7 +63,21 @@ __global__ __launch_bounds__(256) void sphere_backward_kernel(const T* __restric
   // pass 1: gF (kept in `out`) and F . gF
   for (int d = tid; d < D; d += 256) {
     T g = extra != nullptr ? extra[(size_t)k * D + d] : T(0);
-    for (int q = 0; q < n_groups; ++q) g += partials[((size_t)q * K + k) * D + d];  // fixed order
+    // four interleaved partial sums (fixed association: reproducible) keep the loads independent: the
+    // kernel has only K workgroups and is bound by the latency of these L2 reads
+    T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
+    const T* pp = partials + (size_t)k * D + d;
+    const size_t stride = (size_t)K * D;
+    int q = 0;
+#pragma unroll 2
+    for (; q + 4 <= n_groups; q += 4) {
+      a0 += pp[(size_t)q * stride];
+      a1 += pp[(size_t)(q + 1) * stride];
+      a2 += pp[(size_t)(q + 2) * stride];
+      a3 += pp[(size_t)(q + 3) * stride];
+    }
+    for (; q < n_groups; ++q) a0 += pp[(size_t)q * stride];
+    g += (a0 + a1) + (a2 + a3);
     out[(size_t)k * D + d] = g;
     dot += (x[d] / nrm) * g;
   }

@@ -485,6 +485,69 @@ __device__ __forceinline__ void cross_rounds_static(T (&x)[CPL][MR], T (&nrm)[CP
   }
 }
 
+// Rotations between the columns of one lane, in tournament order: round t pairs slot c with c ^ t, and
+// the (up to two) pairs of a round that are handled together touch disjoint slots, so their inner
+// products and parameter chains are independent instruction streams (the plain c1 < c2 double loop
+// is one long dependency chain through slot 0: fine with four waves per SIMD, exposed with two).
+#ifndef SQFA_LOCAL_TOURNAMENT
+#define SQFA_LOCAL_TOURNAMENT 1
+#endif
+template <typename T, int MR, int CPL, int A0, int B0, int A1, int B1>
+__device__ __forceinline__ void local_step2(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], T tol2, bool& big) {
+  using R = Real<T>;
+  constexpr int NS = A1 >= 0 ? 2 : 1;
+  constexpr int ca[2] = {A0, A1 >= 0 ? A1 : A0}, cb[2] = {B0, A1 >= 0 ? B1 : B0};
+  T gh[2] = {T(0), T(0)};
+#pragma unroll
+  for (int r = 0; r < MR; ++r) {
+#pragma unroll
+    for (int q = 0; q < NS; ++q) gh[q] = R::fma_(x[ca[q]][r], x[cb[q]][r], gh[q]);
+  }
+  T a1[2], a2[2];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    T u, ru, k, g2;
+    rot_scaled(nrm[ca[q]], nrm[cb[q]], gh[q], D[ca[q]], D[cb[q]], tol2, T(1), u, ru, k, g2, big);
+    const T kgh = k * gh[q], kg2 = k * g2;
+    a1[q] = -(kgh * D[cb[q]]);
+    a2[q] = kgh * D[ca[q]];
+    D[ca[q]] *= u;
+    D[cb[q]] *= u;
+    nrm[ca[q]] -= kg2;
+    nrm[cb[q]] += kg2;
+  }
+#pragma unroll
+  for (int r = 0; r < MR; ++r) {
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      const T xp = x[ca[q]][r];
+      x[ca[q]][r] = R::fma_(a1[q], x[cb[q]][r], xp);
+      x[cb[q]][r] = R::fma_(a2[q], xp, x[cb[q]][r]);
+    }
+  }
+}
+template <typename T, int MR, int CPL, int T_, int CSTART>
+__device__ __forceinline__ void local_t_steps(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], T tol2, bool& big) {
+  constexpr auto valid = [](int c) constexpr { return c < CPL && (c ^ T_) > c && (c ^ T_) < CPL; };
+  constexpr int first = [&]() constexpr { int c = CSTART; while (c < CPL && !valid(c)) ++c; return c; }();
+  if constexpr (first < CPL) {
+    constexpr int second = [&]() constexpr { int c = first + 1; while (c < CPL && !valid(c)) ++c; return c; }();
+    if constexpr (second < CPL) {
+      local_step2<T, MR, CPL, first, first ^ T_, second, second ^ T_>(x, nrm, D, tol2, big);
+      local_t_steps<T, MR, CPL, T_, second + 1>(x, nrm, D, tol2, big);
+    } else {
+      local_step2<T, MR, CPL, first, first ^ T_, -1, -1>(x, nrm, D, tol2, big);
+    }
+  }
+}
+template <typename T, int MR, int CPL, int T_>
+__device__ __forceinline__ void local_rounds(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], T tol2, bool& big) {
+  if constexpr (T_ < pow2ceil(CPL)) {
+    local_t_steps<T, MR, CPL, T_, 0>(x, nrm, D, tol2, big);
+    local_rounds<T, MR, CPL, T_ + 1>(x, nrm, D, tol2, big);
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Transposing tree reduction.  Every lane holds a value for each of 2^LEVEL consecutive
 // indices [BASE, BASE + 2^LEVEL); the sum over the 2^LEVEL lanes of an aligned lane block is
@@ -621,7 +684,10 @@ struct PairCfg {
   static_assert((TJ & (TJ - 1)) == 0, "TJ must be a power of two (run-time halving, shift-based tile search)");
 };
 
-template <typename Cfg>
+// EIG_BWD selects the backward of the eigenvalues themselves (per-eigenvalue weights EWt) at COMPILE time:
+// as a run-time branch it kept six more values alive across the backward phase of the hot instantiation
+// (7 spilled VGPRs instead of 1 at m=16, +20 MB of scratch traffic per launch).
+template <typename Cfg, bool EIG_BWD>
 __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel(
     const PairParams p, const typename Cfg::type* __restrict__ LT,
     const typename Cfg::type* __restrict__ LinvAll, const typename Cfg::type* __restrict__ Wt,
@@ -782,6 +848,9 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
       }
       bool big = false;
       // pairs inside my own lane
+      if constexpr (SQFA_LOCAL_TOURNAMENT && G == 1) {  // measured: m=8 (one lane per pair) -4 %; no change for G >= 4
+        local_rounds<T, MR, CPL, 1>(x, nrm, D, tol2, big);
+      } else {
 #pragma unroll
       for (int c1 = 0; c1 < CPL; ++c1) {
 #pragma unroll
@@ -804,6 +873,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
           nrm[c1] -= kg2;
           nrm[c2] += kg2;
         }
+      }
       }
       // pairs across the lanes of my group
       if constexpr (G > 1 && G <= Cfg::STATIC_G) {
@@ -890,7 +960,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
         coefB[c] = -q;
         coefA[c] = q / lam[c];
       }
-      if (EWt != nullptr) {
+      if constexpr (EIG_BWD) {
         // backward of the eigenvalues themselves: d lambda_k/dA = u u^T = u~ u~^T / lambda_k,
         // d lambda_k/dB = -lambda_k u u^T = -u~ u~^T  (u~ = sigma_k u).  Self mode also carries the
         // mirrored entry eig[j,i,k] = 1/lambda_k, whose derivative is -1/lambda_k^2.
@@ -996,8 +1066,12 @@ hipError_t launch_pair_tiles(const PairParams& p, hipStream_t stream) {
   if (n_tiles == 0) return hipSuccess;  // this shard owns no tile (more shards than tiles)
   dim3 grid((unsigned)n_tiles, 1, 1);
   using T = typename Cfg::type;
-  hipLaunchKernelGGL((pair_tile_kernel<Cfg>), grid, dim3(Cfg::THREADS), 0, stream, p, static_cast<const T*>(p.LT),
-                     static_cast<const T*>(p.Linv), static_cast<const T*>(p.W), static_cast<const T*>(p.EW));
+  if (p.EW != nullptr)
+    hipLaunchKernelGGL((pair_tile_kernel<Cfg, true>), grid, dim3(Cfg::THREADS), 0, stream, p, static_cast<const T*>(p.LT),
+                       static_cast<const T*>(p.Linv), static_cast<const T*>(p.W), static_cast<const T*>(p.EW));
+  else
+    hipLaunchKernelGGL((pair_tile_kernel<Cfg, false>), grid, dim3(Cfg::THREADS), 0, stream, p, static_cast<const T*>(p.LT),
+                       static_cast<const T*>(p.Linv), static_cast<const T*>(p.W), static_cast<const T*>(p.EW));
   return hipGetLastError();
 }
 

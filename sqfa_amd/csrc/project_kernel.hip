@@ -20,6 +20,7 @@
 // float64 uses v_mfma_f64_16x16x4_f64 with 2 columns per lane (same 16-byte loads) and that
 // instruction's own C/D row map (row = (l>>4) + 4*reg).
 #include <hip/hip_runtime.h>
+#include <mutex>
 
 #include <utility>
 #include <vector>
@@ -29,6 +30,7 @@
 
 bool sqfa_profile_enabled();                                            // sqfa_api.hip
 std::vector<std::pair<hipEvent_t, hipEvent_t>>& sqfa_project_events();  // sqfa_api.hip
+std::mutex& sqfa_project_events_mutex();                                 // sqfa_api.hip
 
 namespace sqfa {
 
@@ -158,6 +160,7 @@ extern "C" int sqfa_project_scatters(const void* F, int K, int D, const void* Ps
     launch_project(static_cast<const double*>(F), static_cast<const double*>(Psi), static_cast<double*>(T_out), C, D, K, stream);
   if (prof) {
     (void)hipEventRecord(e1, stream);
+    std::lock_guard<std::mutex> lock(sqfa_project_events_mutex());
     sqfa_project_events().emplace_back(e0, e1);
   }
   return hipGetLastError() == hipSuccess ? SQFA_OK : SQFA_ERR_LAUNCH;

@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -48,12 +49,17 @@ static unsigned long long* g_sweep_counter = nullptr;
 struct EventPair { hipEvent_t a, b; };
 static bool g_profile = false;
 static std::vector<EventPair> g_events;
+static std::mutex g_events_mutex;  // the event lists are shared by every host thread that calls into the library
 }  // namespace sqfa
 // shared with project_kernel.hip
 bool sqfa_profile_enabled() { return sqfa::g_profile; }
 std::vector<std::pair<hipEvent_t, hipEvent_t>>& sqfa_project_events() {
   static std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   return ev;
+}
+std::mutex& sqfa_project_events_mutex() {
+  static std::mutex m;
+  return m;
 }
 namespace sqfa {
 
@@ -95,14 +101,30 @@ static bool width_allowed(int nA, int nBeff, const Geometry& g, int tj, int self
   return shard_tiles(nA, nBeff, g, tj, self_mode, 0, 1) <= 16L * resident_workgroups();
 }
 
-// The workspace is sized for the narrowest tiles a launch may choose (most tiles, largest slab).
-static WorkspaceLayout layout(int nA, int nBeff, const Geometry& g, size_t esz, int self_mode) {
+// Tile width a call with `shard_count` shards uses: halved while a shard's launch would leave workgroup
+// slots empty.  Decided from the TOTAL tile count and shard_count only, so that every shard of a job
+// picks the same tiling (tile ownership (bi + bj) % shard_count is defined on that tiling).
+static int choose_tile_width(int nA, int nBeff, const Geometry& g, int self_mode, int shard_count) {
+  int tj = g.TJ;
+  while (tj % 2 == 0 && width_allowed(nA, nBeff, g, tj / 2, self_mode) &&
+         shard_tiles(nA, nBeff, g, tj, self_mode, 0, 1) / shard_count < resident_workgroups())
+    tj /= 2;
+  return tj;
+}
+
+// Workspace for one tiling (only_tj > 0: exactly the tile width a call will use), or for the narrowest
+// tiles any call may choose (only_tj == 0: most tiles, largest slab).
+static WorkspaceLayout layout(int nA, int nBeff, const Geometry& g, size_t esz, int self_mode, int only_tj = 0) {
   WorkspaceLayout w;
   const size_t mat = (size_t)g.MR * g.MR * esz;
   const size_t tri = (size_t)g.MR * (g.MR + 1) / 2;
   const size_t nbi = (nA + g.TI - 1) / g.TI;
   size_t slab = 0, tiles = 0;
   for (int tj = g.TJ; tj >= 1 && width_allowed(nA, nBeff, g, tj, self_mode); tj /= 2) {
+    if (only_tj > 0 && tj != only_tj) {
+      if (tj % 2) break;
+      continue;
+    }
     const size_t nbj = (nBeff + tj - 1) / tj;
     slab = std::max(slab, nbi * nbj * (size_t)(g.TI + tj) * tri * esz);
     tiles = std::max(tiles, nbi * nbj);
@@ -210,8 +232,11 @@ __device__ inline bool tile_processed(const PairParams& p, int bi, int bj, int T
   return true;
 }
 
+#ifndef SQFA_K2_THREADS
+#define SQFA_K2_THREADS 512  // 1024 threads (7 summation groups per class instead of 3): 29 vs 28 us at c3, no gain
+#endif
 template <typename T>
-__global__ __launch_bounds__(512) void finalize_kernel(const PairParams p, int TI, int TJ, int MR,
+__global__ __launch_bounds__(SQFA_K2_THREADS) void finalize_kernel(const PairParams p, int TI, int TJ, int MR,
                                                        T* __restrict__ gradA, T* __restrict__ gradB,
                                                        T* __restrict__ loss_out, int* __restrict__ nonfinite_out) {
   const int tid = threadIdx.x;
@@ -229,7 +254,7 @@ __global__ __launch_bounds__(512) void finalize_kernel(const PairParams p, int T
     const size_t tile_stride = (size_t)(TI + TJ) * TRI;
     // NG thread groups each sum every NG-th contributing tile (a fixed subsequence), then the
     // NG partial sums are combined in group order: short dependent chains, bitwise reproducible.
-    int NG = 512 / TRI;
+    int NG = SQFA_K2_THREADS / TRI;
     NG = NG < 1 ? 1 : (NG > 8 ? 8 : NG);
     const int bi_a = c / TI, pi = c % TI, bj_b = c / TJ, pj = c % TJ;
     // Only the tiles this shard owns are visited (same enumeration as the pair kernel's grid):
@@ -242,7 +267,7 @@ __global__ __launch_bounds__(512) void finalize_kernel(const PairParams p, int T
       first_b = ((p.shard_index - bj_b) % N + N) % N;
       n_b = p.nbi > first_b ? (p.nbi - 1 - first_b) / N + 1 : 0;
     }
-    for (int e = tid; e < NG * TRI; e += 512) {
+    for (int e = tid; e < NG * TRI; e += SQFA_K2_THREADS) {
       const int grp = e / TRI, idx = e % TRI;
       T acc = T(0);
       for (int q = grp; q < n_a + n_b; q += NG) {
@@ -257,7 +282,7 @@ __global__ __launch_bounds__(512) void finalize_kernel(const PairParams p, int T
       s_part[grp * 600 + idx] = acc;
     }
     __syncthreads();
-    for (int idx = tid; idx < TRI; idx += 512) {
+    for (int idx = tid; idx < TRI; idx += SQFA_K2_THREADS) {
       T acc = T(0);
       for (int g2 = 0; g2 < NG; ++g2) acc += s_part[g2 * 600 + idx];
       int r = 0;
@@ -271,13 +296,13 @@ __global__ __launch_bounds__(512) void finalize_kernel(const PairParams p, int T
     return;
   }
   // last block: loss, flag, diagonals
-  __shared__ double s_l[512];
-  __shared__ int s_f[512];
-  __shared__ int s_f2[512];
+  __shared__ double s_l[SQFA_K2_THREADS];
+  __shared__ int s_f[SQFA_K2_THREADS];
+  __shared__ int s_f2[SQFA_K2_THREADS];
   double l = 0.0;
   int f = 0, f2 = 0;
   const int ntiles = p.nbi * p.nbj;
-  for (int tix = tid; tix < ntiles; tix += 512) {
+  for (int tix = tid; tix < ntiles; tix += SQFA_K2_THREADS) {
     const int bi = tix / p.nbj, bj = tix % p.nbj;
     if (tile_processed(p, bi, bj, TI, TJ)) {
       l += (double)static_cast<const T*>(p.slab_loss)[tix];
@@ -289,7 +314,7 @@ __global__ __launch_bounds__(512) void finalize_kernel(const PairParams p, int T
   s_f[tid] = f;
   s_f2[tid] = f2;
   __syncthreads();
-  for (int st = 256; st > 0; st >>= 1) {
+  for (int st = SQFA_K2_THREADS / 2; st > 0; st >>= 1) {
     if (tid < st) {
       s_l[tid] += s_l[tid + st];
       s_f[tid] += s_f[tid + st];
@@ -308,11 +333,11 @@ __global__ __launch_bounds__(512) void finalize_kernel(const PairParams p, int T
     if (p.dist_out != nullptr) {
       T* D = static_cast<T*>(p.dist_out);
       const T dv = p.sqrt_mode ? (T)sqrt(p.eps) : T(0);
-      for (int c = tid; c < p.nA; c += 512) D[(size_t)c * p.nB + c] = dv;
+      for (int c = tid; c < p.nA; c += SQFA_K2_THREADS) D[(size_t)c * p.nB + c] = dv;
     }
     if (p.eig_out != nullptr) {
       T* E = static_cast<T*>(p.eig_out);
-      for (int k = tid; k < p.nA * p.m; k += 512) {
+      for (int k = tid; k < p.nA * p.m; k += SQFA_K2_THREADS) {
         const int c = k / p.m, q = k % p.m;
         E[((size_t)c * p.nB + c) * p.m + q] = T(1);
       }
@@ -349,6 +374,7 @@ int sqfa_airm_profile(int enable) {
 int sqfa_airm_profile_read(double* tile_kernel_ms_total, int* launches) {
   double total = 0.0;
   int n = 0;
+  std::lock_guard<std::mutex> lock(g_events_mutex);
   for (auto& ev : g_events) {
     float ms = 0.f;
     if (hipEventSynchronize(ev.b) == hipSuccess && hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
@@ -367,6 +393,7 @@ int sqfa_airm_profile_read(double* tile_kernel_ms_total, int* launches) {
 int sqfa_project_profile_read(double* kernel_ms_total, int* launches) {
   double total = 0.0;
   int n = 0;
+  std::lock_guard<std::mutex> lock(sqfa_project_events_mutex());
   for (auto& ev : sqfa_project_events()) {
     float ms = 0.f;
     if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
@@ -425,12 +452,9 @@ static int pairwise_impl(const void* A, int nA, const void* B, int nB, int m, in
   // tile width: halve while a shard's launch would leave workgroup slots empty.  Decided from
   // the TOTAL tile count and shard_count only, so that every shard of a job picks the same
   // tiling (tile ownership (bi + bj) % shard_count is defined on that tiling).
-  int tj = g.TJ;
-  while (tj % 2 == 0 && width_allowed(nA, nBeff, g, tj / 2, self_mode ? 1 : 0) &&
-         shard_tiles(nA, nBeff, g, tj, self_mode ? 1 : 0, 0, 1) / shard_count < resident_workgroups())
-    tj /= 2;
+  const int tj = choose_tile_width(nA, nBeff, g, self_mode ? 1 : 0, shard_count);
   const int nbi = (nA + g.TI - 1) / g.TI, nbj = (nBeff + tj - 1) / tj;
-  const WorkspaceLayout w = layout(nA, nBeff, g, esz, self_mode ? 1 : 0);
+  const WorkspaceLayout w = layout(nA, nBeff, g, esz, self_mode ? 1 : 0, tj);
   if (workspace_bytes < w.total) return fail(SQFA_ERR_WORKSPACE, "workspace too small", hipSuccess);
   char* ws = static_cast<char*>(workspace);
 
@@ -504,6 +528,7 @@ static int pairwise_impl(const void* A, int nA, const void* B, int nB, int m, in
   e = g.launch(p, stream);
   if (g_profile) {
     (void)hipEventRecord(ev.b, stream);
+    std::lock_guard<std::mutex> lock(g_events_mutex);
     g_events.push_back(ev);
   }
   if (e != hipSuccess) return fail(SQFA_ERR_LAUNCH, "pair_tile_kernel", e);
@@ -511,17 +536,27 @@ static int pairwise_impl(const void* A, int nA, const void* B, int nB, int m, in
   // K2: slab reduction
   const int n_cls = nA + (self_mode ? 0 : nB);
   if (dtype == SQFA_F32) {
-    hipLaunchKernelGGL(finalize_kernel<float>, dim3(n_cls + 1), dim3(512), 0, stream, p, g.TI, tj, g.MR,
+    hipLaunchKernelGGL(finalize_kernel<float>, dim3(n_cls + 1), dim3(SQFA_K2_THREADS), 0, stream, p, g.TI, tj, g.MR,
                        static_cast<float*>(gradA_out), static_cast<float*>(gradB_out),
                        static_cast<float*>(loss_out), nonfinite_out);
   } else {
-    hipLaunchKernelGGL(finalize_kernel<double>, dim3(n_cls + 1), dim3(512), 0, stream, p, g.TI, tj, g.MR,
+    hipLaunchKernelGGL(finalize_kernel<double>, dim3(n_cls + 1), dim3(SQFA_K2_THREADS), 0, stream, p, g.TI, tj, g.MR,
                        static_cast<double*>(gradA_out), static_cast<double*>(gradB_out),
                        static_cast<double*>(loss_out), nonfinite_out);
   }
   e = hipGetLastError();
   if (e != hipSuccess) return fail(SQFA_ERR_LAUNCH, "finalize_kernel", e);
   return SQFA_OK;
+}
+
+size_t sqfa_airm_workspace_bytes_sharded(int nA, int nB, int m, int dtype, int shard_count) {
+  int ti, tj, nbi, nbj, mr;
+  if (shard_count < 1 || sqfa_airm_tiling(nA, nB, m, dtype, &ti, &tj, &nbi, &nbj, &mr) != SQFA_OK) return 0;
+  Geometry g;
+  find_geometry(m, dtype, &g);
+  const int nBeff = nB == 0 ? nA : nB, self_mode = nB == 0 ? 1 : 0;
+  return layout(nA, nBeff, g, dtype == SQFA_F32 ? 4 : 8, self_mode,
+                choose_tile_width(nA, nBeff, g, self_mode, shard_count)).total;
 }
 
 int sqfa_airm_pairwise(const void* A, int nA, const void* B, int nB, int m, int dtype, double scale,

@@ -39,7 +39,7 @@ def test_cpu_baseline_leg_runs_the_oracle():
 
 
 def test_pmc_summary_is_consistent():
-    with open(os.path.join(ROOT, "profiles", "r1_pmc_c3.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", bench.PMC_FILE)) as fh:
         pmc = json.load(fh)["kernels"]
     assert abs(pmc["project_kernel"]["algorithmic_bytes_per_launch"] - 4 * 1000 * 784 * 784) < 1
     assert 0.9 < pmc["project_kernel"]["hbm_bytes_per_launch"] / pmc["project_kernel"]["algorithmic_bytes_per_launch"] < 1.3

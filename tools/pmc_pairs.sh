@@ -1,7 +1,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/r2/pmc_base
+OUT=$R/gpurun_out/r2/${PMC_NAME:-pmc_pairs}
 mkdir -p $OUT
 cd $R
 SPECS="1000:16:smsqfa 1000:16:sqfa 1000:32:smsqfa 1000:32:sqfa"
