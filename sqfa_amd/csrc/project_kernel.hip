@@ -148,7 +148,11 @@ extern "C" int sqfa_project_scatters(const void* F, int K, int D, const void* Ps
   if (F == nullptr || Psi == nullptr || T_out == nullptr || K < 1 || D < 4 || C < 1) return SQFA_ERR_BAD_ARGUMENT;
   if ((dtype != SQFA_F32 && dtype != SQFA_F64) || (D % 4) != 0 || K > 64 || K > D) return SQFA_ERR_UNSUPPORTED_M;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  const bool prof = sqfa_profile_enabled();
+  bool prof = sqfa_profile_enabled();
+  if (prof) {  // no event records inside a captured graph
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) prof = false;
+  }
   if (prof) {
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);

@@ -520,13 +520,18 @@ static int pairwise_impl(const void* A, int nA, const void* B, int nB, int m, in
 
   // K1: pair tiles
   EventPair ev{};
-  if (g_profile) {
+  bool prof = g_profile;
+  if (prof) {  // event records do not belong in a captured graph: profile eager launches only
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) prof = false;
+  }
+  if (prof) {
     (void)hipEventCreate(&ev.a);
     (void)hipEventCreate(&ev.b);
     (void)hipEventRecord(ev.a, stream);
   }
   e = g.launch(p, stream);
-  if (g_profile) {
+  if (prof) {
     (void)hipEventRecord(ev.b, stream);
     std::lock_guard<std::mutex> lock(g_events_mutex);
     g_events.push_back(ev);

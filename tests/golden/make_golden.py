@@ -612,6 +612,38 @@ def g7c():
     torch.set_default_dtype(torch.float32)
 
 
+# ---------------------------------------------------------------- G3b: transform_scatters at BASELINE shapes
+def g3b():
+    """The reference's transform_scatters / transform (src/sqfa/model.py:172-237, conjugate_matrix
+    src/sqfa/linalg.py:19-45) on c3- and c4-shaped inputs regenerated from seeds by the tests
+    (c2_statistics(C, D)): values and the gradient of a weighted sum wrt the raw filter parameter."""
+    out = {}
+    for (C, D, K) in ((3, 784, 16), (2, 2048, 32), (4, 132, 8)):
+        key = f"C{C}_D{D}_K{K}"
+        stats = c2_statistics(C=C, D=D)
+        rng = np.random.default_rng(1000 + D + K)
+        raw = rng.standard_normal((K, D))
+        W = rng.standard_normal((C, K, K))
+        out[f"{key}_raw"], out[f"{key}_W"] = raw, W
+        out[f"{key}_check"] = stats["covariances"][0, :3, :3].numpy()
+        for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            torch.set_default_dtype(dt)
+            model = sqfa.model.SecondMomentsSQFA(n_dim=D, n_filters=K, feature_noise=0.0)
+            if dt == torch.float64:
+                model = model.double()
+            with torch.no_grad():
+                model.parametrizations.filters.original.copy_(T(raw, dt))
+            S = model.transform_scatters(stats["covariances"].to(dt))
+            Z = model.transform(stats["means"].to(dt))
+            loss = torch.sum(T(W, dt) * S)
+            loss.backward()
+            out[f"{key}_S_{tag}"] = S.detach().numpy()
+            out[f"{key}_Z_{tag}"] = Z.detach().numpy()
+            out[f"{key}_grad_{tag}"] = model.parametrizations.filters.original.grad.numpy()
+    torch.set_default_dtype(torch.float32)
+    np.savez_compressed(os.path.join(HERE, "g3b_transform_scatters.npz"), **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g1x", "g2", "g3", "g4", "g5"]
     for name in which:

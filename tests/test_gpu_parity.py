@@ -375,3 +375,35 @@ def test_transform_scatters_nonsymmetric_input_takes_general_path():
     assert rel_err(model.parametrizations.filters.original.grad.cpu(), Fr.grad.cpu()) < 1e-12
     sym = Psi @ Psi.transpose(1, 2)                       # GEMM-built: symmetric up to rounding
     assert _native.native_projection_supported(sym, model.filters)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("C,D,K", [(3, 784, 16), (2, 2048, 32), (4, 132, 8)])
+def test_transform_scatters_vs_reference_golden(C, D, K, dtype):
+    """transform_scatters / transform through the streaming projection kernels against the REFERENCE's
+    outputs (golden G3b: src/sqfa/model.py:172-237 evaluated by importing the reference) at the c3 / c4
+    shapes: values and the gradient of a weighted sum with respect to the raw filter parameter."""
+    import model_cases as mc
+    import sqfa_amd
+    from sqfa_amd import _native
+    G3B = load_golden("g3b_transform_scatters.npz")
+    key = f"C{C}_D{D}_K{K}"
+    stats = mc.c2_statistics(C=C, D=D)
+    assert np.allclose(stats["covariances"][0, :3, :3].numpy(), G3B[f"{key}_check"], rtol=1e-12)
+    cov = stats["covariances"].to(dtype).to(DEV)
+    with mc.default_dtype(dtype):
+        model = sqfa_amd.model.SecondMomentsSQFA(n_dim=D, n_filters=K, feature_noise=0.0)
+    model = (model.double() if dtype == torch.float64 else model).to(DEV)
+    with torch.no_grad():
+        model.parametrizations.filters.original.copy_(torch.tensor(G3B[f"{key}_raw"], dtype=dtype))
+    assert _native.native_projection_supported(cov, model.filters)
+    S = model.transform_scatters(cov)
+    Z = model.transform(stats["means"].to(dtype).to(DEV))
+    f64 = dtype == torch.float64
+    dev_S = rel_err(G3B[f"{key}_S_f32"], G3B[f"{key}_S_f64"])
+    dev_g = rel_err(G3B[f"{key}_grad_f32"], G3B[f"{key}_grad_f64"])
+    assert rel_err(S.detach().cpu(), G3B[f"{key}_S_f64"]) <= (1e-12 if f64 else max(2e-6, 5 * dev_S))
+    assert rel_err(Z.detach().cpu(), G3B[f"{key}_Z_f64"]) <= (1e-12 if f64 else 2e-6)
+    (torch.tensor(G3B[f"{key}_W"], dtype=dtype, device=DEV) * S).sum().backward()
+    g = model.parametrizations.filters.original.grad
+    assert rel_err(g.cpu(), G3B[f"{key}_grad_f64"]) <= (1e-11 if f64 else max(5e-6, 5 * dev_g))
