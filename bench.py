@@ -250,14 +250,35 @@ def spawn_ranks(n, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode]
-    for p in procs[1:]:
+    # rank 0's stdout is drained by a thread; meanwhile watch every child: if one dies with an error the
+    # others would wait for it in a collective forever, so the remaining ranks are stopped (exact PIDs)
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while procs[0].poll() is None:
+        for r, p in enumerate(procs[1:], start=1):
+            rc = p.poll()
+            if rc not in (None, 0):
+                failed = (r, rc)
+        if failed is not None:
+            break
+        time.sleep(0.2)
+    if failed is not None:
+        sys.stderr.write(f"bench.py: rank {failed[0]} exited with code {failed[1]}; stopping the other ranks\n")
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    codes = []
+    for p in procs:
         try:
             codes.append(p.wait(timeout=120))
         except subprocess.TimeoutExpired:  # rank 0 is gone: a rank still alive is stuck in a collective
             p.kill()
             codes.append(p.wait())
+    reader.join(timeout=10)
+    out = b"".join(c for c in chunks if c)
     for line in out.decode().splitlines():   # stdout carries the JSON line only (libraries' chatter -> stderr)
         (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
@@ -284,6 +305,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.launcher_selftest:  # CPU check of the launcher: no GPU, no process group
+        if os.environ.get("SQFA_BENCH_SELFTEST_FAIL_RANK") == str(rank):
+            raise SystemExit(7)          # a rank that dies: the launcher must stop the others and report it
+        if os.environ.get("SQFA_BENCH_SELFTEST_FAIL_RANK") is not None:
+            time.sleep(60)               # ... while they would wait for it in a collective
         if rank == 0:
             print(json.dumps({"selftest": True, "world": world, "rank": rank, "local_rank": local_rank,
                               "master": os.environ.get("MASTER_ADDR"), "port": int(os.environ.get("MASTER_PORT", "0"))}))

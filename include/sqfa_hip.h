@@ -181,6 +181,21 @@ int sqfa_sphere_backward(const void *X, const void *norms, int K, int D, int dty
                          const void *extra, const void *gloss, void *grad_out, void *stream);
 
 /*
+ * L-BFGS search direction in compact form for optimizer state kept on the device (the reference optimises
+ * with torch.optim.LBFGS, src/sqfa/_optim.py:78-82; this evaluates the same two-loop recursion as two
+ * triangular solves and four (history x n) products in six launches, sqfa_amd/_lbfgs.py).
+ *   S, Y (h, n): ring buffers of steps and gradient differences; SY (h, h): SY[i][j] = s_i . y_j; h <= 128
+ *   sqfa_lbfgs_push        writes (s, y) into ring row `slot` and refreshes row and column `slot` of SY
+ *   sqfa_lbfgs_direction   d_out (n) = -H g for the k pairs listed (HOST array `slots`, chronological order);
+ *                          H_diag: device scalar (initial Hessian scale) or NULL = 1; work: 3 h + n elements
+ */
+int sqfa_lbfgs_max_history(void);
+int sqfa_lbfgs_push(void *S, void *Y, void *SY, int h, int n, int slot, const void *s, const void *y, int dtype,
+                    void *stream);
+int sqfa_lbfgs_direction(const void *S, const void *Y, const void *SY, int h, int n, const int *slots, int k,
+                         const void *g, const void *H_diag, void *d_out, void *work, int dtype, void *stream);
+
+/*
  * Per-pair Gaussian terms behind the reference's other distance_fun operators -- bhattacharyya
  * (src/sqfa/distances.py:240-280), mahalanobis[_sq] (:283-361), hellinger (:364-393),
  * fisher_rao_same_cov (:396-432) -- which all reduce to, with Sbar_ij = (Sigma_i + Sigma_j)/2 and

@@ -24,6 +24,10 @@ import torch
 class _History:
     """Ring buffers for the (s, y) pairs; `slots` lists the ring rows in chronological order."""
 
+    # device-resident history: push / direction through the library's six-launch compact form
+    # (sqfa_lbfgs_push / sqfa_lbfgs_direction) instead of ~35 torch launches and an index upload
+    native = True
+
     def __init__(self, size, like):
         n = like.numel()
         self.size = size
@@ -31,6 +35,19 @@ class _History:
         self.Y = like.new_zeros(size, n)
         self.SY = like.new_zeros(size, size)
         self.slots = []
+        self._lib = None
+        if self.native and like.is_cuda and like.dtype in (torch.float32, torch.float64):
+            from . import _lib
+            lib = _lib.load()
+            if size <= lib.sqfa_lbfgs_max_history():
+                self._lib = lib
+                self._check = _lib.check
+                self._code = _lib.SQFA_F32 if like.dtype == torch.float32 else _lib.SQFA_F64
+                self._work = like.new_empty(3 * size + n)
+
+    def _stream(self):
+        import ctypes
+        return ctypes.c_void_p(torch.cuda.current_stream(self.S.device).cuda_stream)
 
     def push(self, y, s):
         if len(self.slots) == self.size:
@@ -38,6 +55,13 @@ class _History:
         else:
             slot = len(self.slots)
         self.slots.append(slot)
+        if self._lib is not None:
+            s, y = s.contiguous(), y.contiguous()
+            with torch.cuda.device(self.S.device):
+                self._check(self._lib.sqfa_lbfgs_push(self.S.data_ptr(), self.Y.data_ptr(), self.SY.data_ptr(), self.size,
+                                                      self.S.shape[1], slot, s.data_ptr(), y.data_ptr(), self._code,
+                                                      self._stream()), "sqfa_lbfgs_push")
+            return
         self.S[slot] = s
         self.Y[slot] = y
         self.SY[slot, :] = self.Y @ s   # s_new . y_j
@@ -48,6 +72,21 @@ class _History:
         k = len(self.slots)
         if k == 0:
             return q0 * H_diag
+        if self._lib is not None:
+            import ctypes
+            g = flat_grad.contiguous()
+            d = torch.empty_like(g)
+            H = H_diag if torch.is_tensor(H_diag) else (None if H_diag == 1 else g.new_tensor(float(H_diag)))
+            if H is not None:
+                H = H.to(g.dtype).reshape(1).contiguous()
+            slots = (ctypes.c_int * k)(*self.slots)
+            with torch.cuda.device(g.device):
+                self._check(self._lib.sqfa_lbfgs_direction(self.S.data_ptr(), self.Y.data_ptr(), self.SY.data_ptr(), self.size,
+                                                           g.numel(), slots, k, g.data_ptr(),
+                                                           H.data_ptr() if H is not None else None, d.data_ptr(),
+                                                           self._work.data_ptr(), self._code, self._stream()),
+                            "sqfa_lbfgs_direction")
+            return d
         idx = torch.as_tensor(self.slots, device=flat_grad.device)
         SY = self.SY.index_select(0, idx).index_select(1, idx)  # chronological k x k
         b0 = (self.S @ q0).index_select(0, idx)

@@ -87,6 +87,17 @@ PROTOTYPES = {
         [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
     ),
+    "sqfa_lbfgs_max_history": (ctypes.c_int, []),
+    "sqfa_lbfgs_push": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p],
+    ),
+    "sqfa_lbfgs_direction": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+         ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p],
+    ),
     "sqfa_airm_set_sweep_counter": (ctypes.c_int, [ctypes.c_void_p]),
     "sqfa_airm_profile": (ctypes.c_int, [ctypes.c_int]),
     "sqfa_airm_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), _c_int_p]),

@@ -56,3 +56,15 @@ def test_bench_spawns_its_own_ranks():
     assert out.returncode == 0, out.stderr
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["world"] == 3 and line["rank"] == 0 and line["master"] == "127.0.0.1" and line["port"] > 0
+
+
+def test_bench_launcher_stops_the_job_when_a_rank_dies():
+    import subprocess
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["SQFA_BENCH_SELFTEST_FAIL_RANK"] = "1"
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-selftest"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "rank 1 exited with code 7" in out.stderr
+    assert time.time() - t0 < 45          # did not sit out the other rank's wait

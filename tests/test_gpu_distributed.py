@@ -201,3 +201,29 @@ def test_sharded_closure_runs_as_two_graphs_around_one_all_reduce():
     assert cs["cpu"] <= closures + 2, (cs, closures)      # one read-back per closure
     assert np.abs(ls - le).max() < 1e-12 and np.linalg.norm(Fs - Fe) < 1e-10 * np.linalg.norm(Fe)
     assert np.abs(ls - l1).max() < 1e-9 and np.linalg.norm(Fs - F1) < 1e-8 * np.linalg.norm(F1)
+
+
+@pytest.mark.timeout(600)
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 2` by itself: the launcher starts both ranks; on a
+    one-GPU box they share cuda:0 over gloo (SQFA_BENCH_REHEARSAL=1).  One JSON line, n_gpus = 2, the same
+    loss as the single-process run, the c4 pair leg present."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["SQFA_BENCH_REHEARSAL"] = "1"
+    args = ["--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--workload", "c2"]
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, env=env,
+                         capture_output=True, text=True, timeout=500)
+    assert two.returncode == 0, two.stderr[-2000:]
+    lines = [l for l in two.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    r2 = json.loads(lines[0])
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-closure"] + args, env=env,
+                         capture_output=True, text=True, timeout=500)
+    assert one.returncode == 0, one.stderr[-2000:]
+    r1 = json.loads(one.stdout.strip().splitlines()[-1])
+    assert r2["n_gpus"] == 2 and r2["scaling"] == "strong" and r2["unit"] == "evals/s" and r2["value"] > 0
+    assert abs(r2["loss"] - r1["loss"]) < 1e-5 * abs(r1["loss"])
+    assert r2["scaling_c4_pairs"]["n_gpus"] == 2 and r2["scaling_c4_pairs"]["value"] > 0
+    assert r2["roofline"]["bound"] == "valu" and 0 < r2["roofline"]["frac"] < 1

@@ -55,3 +55,40 @@ def test_line_search_defers_to_torch():
     l0 = opt.step(closure).item()
     l1 = opt.step(closure).item()
     assert l1 < l0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-11), (torch.float32, 2e-4)])
+@pytest.mark.parametrize("n,h,pushes", [(300, 7, 5), (12544, 100, 130), (50000, 20, 45)])
+def test_native_lbfgs_direction_matches_torch_compact_form(n, h, pushes, dtype, tol):
+    """sqfa_lbfgs_push / sqfa_lbfgs_direction (six launches) against the torch compact form of the same
+    recursion: same ring buffers, same SY, same direction, also after the ring has wrapped around."""
+    from sqfa_amd._lbfgs import _History
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(n + h)
+    like = torch.zeros(n, dtype=dtype, device=dev)
+    nat, ref = _History(h, like), None
+    saved = _History.native
+    try:
+        _History.native = False
+        ref = _History(h, like)
+    finally:
+        _History.native = saved
+    assert nat._lib is not None and ref._lib is None
+    B = torch.randn(n, 8, generator=gen, dtype=torch.float64)
+    for it in range(pushes):
+        s = torch.randn(n, generator=gen, dtype=torch.float64)
+        y = s + 0.3 * (B @ (B.T @ s)) / n                  # y = (I + low rank PSD) s: s.y > 0
+        s, y = s.to(dtype).to(dev), y.to(dtype).to(dev)
+        nat.push(y, s)
+        ref.push(y, s)
+        if it in (0, 3, pushes - 1):
+            g = torch.randn(n, generator=gen, dtype=torch.float64).to(dtype).to(dev)
+            H = (s.dot(y) / y.dot(y))
+            d_nat, d_ref = nat.direction(g, H), ref.direction(g, H)
+            assert torch.linalg.norm(d_nat - d_ref) <= tol * torch.linalg.norm(d_ref)
+    assert nat.slots == ref.slots
+    idx = torch.as_tensor(nat.slots, device=dev)
+    assert torch.allclose(nat.SY.index_select(0, idx).index_select(1, idx), ref.SY.index_select(0, idx).index_select(1, idx),
+                          rtol=1e-10 if dtype == torch.float64 else 1e-4, atol=1e-12 if dtype == torch.float64 else 1e-3)
+    assert torch.equal(nat.S, ref.S) and torch.equal(nat.Y, ref.Y)
