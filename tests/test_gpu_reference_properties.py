@@ -70,3 +70,46 @@ def test_generalized_eigenvalues_vs_scipy(nA, nB, n_dim):
         for j in range(nB):
             ref[i, j] = np.sort(scipy.linalg.eigvals(A[i].numpy(), B[j].numpy()).real)[::-1]
     assert np.allclose(lam.numpy().reshape(nA, nB, n_dim), ref, atol=1e-9)
+
+
+@pytest.mark.parametrize("dtype,atol", [(torch.float64, 1e-10), (torch.float32, 1e-5)])
+@pytest.mark.parametrize("n_classes", [1, 4, 8])
+@pytest.mark.parametrize("n_dim", [2, 4, 6])
+def test_bhattacharyya(n_classes, n_dim, dtype, atol):
+    """reference tests/test_distances.py:127-151 on the native Gaussian pair kernel: shape incl. the
+    single-class squeeze, symmetry, zero diagonal."""
+    from sqfa_amd import distances
+    spd = sample_spd(n_classes, n_dim, 17 * n_classes + n_dim).to(DEV, dtype)
+    mu = torch.randn(n_classes, n_dim, dtype=torch.float64, generator=torch.Generator().manual_seed(5)).to(DEV, dtype)
+    if n_classes == 1:
+        spd, mu = spd.squeeze(0), mu.squeeze(0)
+    st = {"means": mu, "covariances": spd}
+    bh = distances.bhattacharyya(st, st)
+    assert bh.shape == ((n_classes, n_classes) if n_classes != 1 else ())
+    assert torch.allclose(bh, bh.T if bh.dim() else bh, atol=atol)
+    diag = bh.diagonal() if bh.dim() else bh
+    assert torch.allclose(diag, torch.zeros_like(diag), atol=atol)
+    he = distances.hellinger(st, st)
+    assert he.shape == bh.shape and torch.isfinite(he).all()
+
+
+@pytest.mark.parametrize("dtype,atol", [(torch.float64, 1e-10), (torch.float32, 1e-5)])
+@pytest.mark.parametrize("n_classes", [1, 4, 8])
+@pytest.mark.parametrize("n_dim", [2, 4, 6])
+def test_mahalanobis(n_classes, n_dim, dtype, atol):
+    """reference tests/test_distances.py:154-184: with covariances 2 I the Mahalanobis distance is the
+    Euclidean distance / sqrt(2) (after subtracting the sqrt(eps) of the diagonal)."""
+    from sqfa_amd import distances
+    spd = (torch.eye(n_dim, dtype=dtype).repeat(n_classes, 1, 1) * 2.0).to(DEV)
+    mu = torch.randn(n_classes, n_dim, dtype=torch.float64, generator=torch.Generator().manual_seed(9)).to(DEV, dtype)
+    st = {"means": mu, "covariances": spd}
+    ma = distances.mahalanobis(st, st)
+    assert ma.shape == (n_classes, n_classes)          # mahalanobis_sq is not squeezed in the reference either
+    ma = ma - torch.eye(n_classes, dtype=dtype, device=DEV) * 1e-3
+    assert torch.allclose(ma, ma.T, atol=atol)
+    assert torch.allclose(ma.diagonal(), torch.zeros(n_classes, dtype=dtype, device=DEV), atol=10 * atol)
+    euclid = torch.cdist(mu, mu, p=2.0) / 2.0 ** 0.5
+    # sqrt(d^2 + 1e-6) - d <= 1e-6 / (2 d): the reference's own tolerance for this comparison is 1e-5
+    assert torch.allclose(ma, euclid, atol=1e-5)
+    fr = distances.fisher_rao_same_cov(st, st)
+    assert fr.shape == (n_classes, n_classes) and torch.isfinite(fr).all()
