@@ -399,11 +399,10 @@ def fused_closure_supported(raw_filters, scatters, means):
     return native_projection_supported(scatters, raw_filters)
 
 
-def closure_stage_forward(raw, scatters, means, noise, scale, sqrt_mode, weight, shard, sphere, fused=None):
-    """Kernels of one closure evaluation up to (and including) the pair kernels, no autograd:
-    sphere -> T = Psi F^T -> [m = mu F^T] -> S | E -> K0/K1/K2.  `fused` (S.numel() + 3 elements), when
-    given, receives [loss, nan, inf, dL/dS...] in place (the all-reduce buffer of a sharded evaluation).
-    Returns a dict with everything the backward stage needs."""
+def closure_stage_project(raw, scatters, means, noise, sphere, out_S=None):
+    """First half of a closure evaluation, no autograd: sphere -> T = Psi F^T -> [m = mu F^T] -> S | E
+    (feature scatters + noise, or their Calvo-Oller embedding), written into `out_S` when given (a slice of
+    the all-gather buffer of a class-sharded evaluation).  Returns what the backward stage needs."""
     lib = _lib.load()
     X = raw.detach().contiguous()
     Psi = scatters.detach()
@@ -421,14 +420,20 @@ def closure_stage_forward(raw, scatters, means, noise, scale, sqrt_mode, weight,
             F, norms = X, None
         T = torch.empty((C, D, K), dtype=dt, device=dev)
         _lib.check(lib.sqfa_project_scatters(_ptr(F), K, D, _ptr(Psi), C, code, _ptr(T), stream), "sqfa_project_scatters")
-        if means is not None:
-            m = torch.matmul(means.detach(), F.t()).contiguous()       # (C,K) projected means
-            S = torch.empty((C, K + 1, K + 1), dtype=dt, device=dev)
-        else:
-            m = None
-            S = torch.empty((C, K, K), dtype=dt, device=dev)
+        msize = K + 1 if means is not None else K
+        m = torch.matmul(means.detach(), F.t()).contiguous() if means is not None else None   # (C,K) projected means
+        S = out_S if out_S is not None else torch.empty((C, msize, msize), dtype=dt, device=dev)
+        if tuple(S.shape) != (C, msize, msize) or not S.is_contiguous():
+            raise ValueError("out_S must be a contiguous (C, m, m) tensor")
         _lib.check(lib.sqfa_feature_scatters_ex(_ptr(F), K, D, _ptr(T), C, code, float(noise), _ptr(m), _ptr(S), stream),
                    "sqfa_feature_scatters_ex")
+    return {"X": X, "norms": norms, "T": T, "m": m, "means": means.detach() if means is not None else None,
+            "S": S, "S_shape": tuple(S.shape), "sphere": sphere}
+
+
+def closure_stage_pairs(S, scale, sqrt_mode, weight, shard, fused=None):
+    """Second half: K0 / K1 / K2 on the (C,m,m) batch.  `fused` (S.numel() + 3 elements), when given, receives
+    [loss, nan, inf, dL/dS...] in place (the all-reduce buffer of a sharded evaluation)."""
     extra = {}
     if fused is not None:
         extra = {"out_loss": fused[0], "out_gradA": fused[3:].view(S.shape)}
@@ -437,9 +442,14 @@ def closure_stage_forward(raw, scatters, means, noise, scale, sqrt_mode, weight,
                         want_dist=False, want_eig=False, **extra)
     if fused is not None:
         fused[1:3].copy_(out["nonfinite"])   # int32 -> real in the copy itself
-    return {"X": X, "norms": norms, "T": T, "m": m, "means": means.detach() if means is not None else None,
-            "S_shape": tuple(S.shape), "loss": out["loss"], "nonfinite": out["nonfinite"], "gS": out["gradA"],
-            "sphere": sphere}
+    return out["loss"], out["nonfinite"], out["gradA"]
+
+
+def closure_stage_forward(raw, scatters, means, noise, scale, sqrt_mode, weight, shard, sphere, fused=None):
+    """Both halves (closure_stage_project + closure_stage_pairs) for statistics that are not class-sharded."""
+    st = closure_stage_project(raw, scatters, means, noise, sphere)
+    st["loss"], st["nonfinite"], st["gS"] = closure_stage_pairs(st["S"], scale, sqrt_mode, weight, shard, fused)
+    return st
 
 
 def closure_stage_backward(st, gS, gloss):
@@ -499,7 +509,7 @@ class FusedClosure(torch.autograd.Function):
             loss, nonfinite, gS = owner.reduce_fused(fused, nonfinite, st["S_shape"])
         elif reducer is not None:
             loss, nonfinite, gS = reducer(loss, nonfinite, gS)
-        ctx.st = {k: v for k, v in st.items() if k not in ("loss", "nonfinite", "gS")}
+        ctx.st = {k: v for k, v in st.items() if k not in ("loss", "nonfinite", "gS", "S")}
         ctx.gS = gS
         ctx.mark_non_differentiable(nonfinite)
         return loss, nonfinite

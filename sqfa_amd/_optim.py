@@ -162,64 +162,101 @@ def fitting_loop(model, data_statistics, max_epochs=200, lr=0.1, atol=1e-6, show
             offset += n
         return host[0]
 
-    # ---- sharded fits (pair tiles over ranks): two captured graphs around the one collective --------
-    # stage A (parametrization -> projection -> pair kernels -> fused buffer [loss, nan, inf, dL/dS])
-    # and stage B (backward product -> class reduction + sphere backward -> packed [loss, nan, inf, grad])
-    # are captured once each; a closure is: replay A, ONE all-reduce of the fused buffer (eager: works for
-    # RCCL and gloo alike), replay B, ONE device-to-host copy.  Needs the single-node closure's conditions
-    # (model._single_node_inputs); other sharded fits stay eager.
+    # ---- sharded fits: captured graphs around the collectives -----------------------------------------
+    # pair tiles over ranks (PairShard):  graph A  = parametrization -> projection -> pair kernels -> fused
+    #   buffer [loss, nan, inf, dL/dS];  ONE all-reduce (eager: RCCL and gloo alike);  graph B = backward ->
+    #   packed [loss, nan, inf, grad];  ONE device-to-host copy per closure.
+    # + class-sharded statistics (ClassShard, large D):  graph A1 = parametrization -> projection of the LOCAL
+    #   classes into their slice of the (C,m,m) batch;  all-gather of the slices;  graph A2 = pair kernels ->
+    #   fused buffer;  all-reduce;  graph B = backward of the local classes;  all-reduce of the filter gradient.
+    # Needs the single-node closure's conditions (model._single_node_inputs); other sharded fits stay eager.
     split = {"state": "off", "calls": 0}
     if (GRAPH_CLOSURE and len(device_params) == 1 and device_params[0].is_cuda
-            and getattr(model, "pair_shard", None) is not None and getattr(model, "class_shard", None) is None
-            and model.pair_shard.world_size > 1
+            and getattr(model, "pair_shard", None) is not None and model.pair_shard.world_size > 1
             and hasattr(model, "_has_fused_closure") and model._has_fused_closure()
-            and hasattr(model, "_single_node_inputs") and model._single_node_inputs(prepared) is not None
+            and hasattr(model, "_single_node_inputs")
+            and model._single_node_inputs(prepared, allow_class_shard=True) is not None
             and model._noise_scalar() is not None):
         split["state"] = "warmup"
 
     def split_stages():
-        """(stage_a, stage_b) closures over static tensors, for eager warm-up and capture."""
+        """Stage functions over static tensors, for eager warm-up and capture."""
         from . import _native, distances
         import torch.distributed as dist
-        raw, scatters, means, sphere = model._single_node_inputs(prepared)
+        raw, scatters, means, sphere = model._single_node_inputs(prepared, allow_class_shard=True)
         _, scale, sqrt_mode = distances.fused_spec(model.distance_fun)
         noise = model._noise_scalar()
-        C, K = scatters.shape[0], raw.shape[0]
+        shard = model.pair_shard
+        cshard = getattr(model, "class_shard", None)
+        C_loc, K = scatters.shape[0], raw.shape[0]
+        C = cshard.n_classes if cshard is not None else C_loc
+        offset = cshard.offset if cshard is not None else 0
         m = K + 1 if means is not None else K
         weight = -1.0 / (C * (C - 1) // 2)
-        shard = model.pair_shard
+        S_full = torch.empty((C, m, m), dtype=scatters.dtype, device=scatters.device)
         fused = torch.empty(C * m * m + 3, dtype=scatters.dtype, device=scatters.device)
         box = {}
+        if cshard is not None:
+            # every rank sends its slice padded to the largest shard (equal sizes: RCCL and gloo alike)
+            n_max = max(cshard.counts)
+            send = torch.zeros((n_max, m, m), dtype=scatters.dtype, device=scatters.device)
+            recv = torch.empty((cshard.world_size, n_max, m, m), dtype=scatters.dtype, device=scatters.device)
+            local_out = send[:C_loc]
+        else:
+            local_out = S_full
 
-        def stage_a():
-            box["st"] = _native.closure_stage_forward(raw, scatters, means, noise, scale, sqrt_mode, weight,
-                                                      shard.shard, sphere, fused)
+        def stage_project():
+            box["st"] = _native.closure_stage_project(raw, scatters, means, noise, sphere, out_S=local_out)
+
+        def gather():
+            if cshard is not None:
+                dist.all_gather([recv[r] for r in range(cshard.world_size)], send, group=cshard.group)
+
+        def stage_pairs():
+            if cshard is not None:
+                start = 0
+                for r, n in enumerate(cshard.counts):
+                    S_full[start:start + n].copy_(recv[r, :n])
+                    start += n
+            _native.closure_stage_pairs(S_full, scale, sqrt_mode, weight, shard.shard, fused)
 
         def reduce():
             dist.all_reduce(fused, op=dist.ReduceOp.SUM, group=shard.group)
 
-        def stage_b():
-            grad = _native.closure_stage_backward(box["st"], fused[3:].view(C, m, m), None)
-            box["grad"] = grad
-            box["packed"] = torch.cat([fused[:3], grad.reshape(-1)])
+        def stage_backward():
+            gS = fused[3:].view(C, m, m)[offset:offset + C_loc]
+            box["grad"] = _native.closure_stage_backward(box["st"], gS, None)
 
-        return stage_a, reduce, stage_b, box
+        def reduce_grad():
+            if cshard is not None:
+                dist.all_reduce(box["grad"], op=dist.ReduceOp.SUM, group=cshard.group)
+
+        def stage_pack():
+            box["packed"] = torch.cat([fused[:3], box["grad"].reshape(-1)])
+
+        return [stage_project, gather, stage_pairs, reduce, stage_backward, reduce_grad, stage_pack], box
 
     def capture_split():
-        stage_a, reduce, stage_b, box = split["stages"]
-        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga):
-            stage_a()
-        reduce()
-        with torch.cuda.graph(gb, pool=ga.pool()):
-            stage_b()
-        split.update(ga=ga, gb=gb, state="on")
+        stages, box = split["stages"]
+        graphs = []
+        pool = None
+        for i, stage in enumerate(stages):
+            if i % 2 == 1:          # the collectives stay eager
+                stage()
+                graphs.append(None)
+                continue
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                stage()
+            pool = g.pool()
+            graphs.append(g)
+        split.update(graphs=graphs, state="on")
 
     def split_closure():
         push_parameters()
         if split.get("stages") is None:
             split["stages"] = split_stages()
-        stage_a, reduce, stage_b, box = split["stages"]
+        stages, box = split["stages"]
         if split["state"] == "warmup" and split["calls"] >= GRAPH_WARMUP_CLOSURES:
             try:
                 capture_split()
@@ -227,14 +264,15 @@ def fitting_loop(model, data_statistics, max_epochs=200, lr=0.1, atol=1e-6, show
                 warnings.warn(f"sqfa_amd: HIP graph capture of the sharded closure failed ({err}); running eagerly")
                 split["state"] = "eager"
         if split["state"] == "on":
-            split["ga"].replay()
-            reduce()
-            split["gb"].replay()
+            for stage, g in zip(stages, split["graphs"]):
+                if g is None:
+                    stage()
+                else:
+                    g.replay()
         else:
             split["calls"] += 1
-            stage_a()
-            reduce()
-            stage_b()
+            for stage in stages:
+                stage()
         packed = box["packed"]
         device_params[0].grad = box["grad"]
         if use_host:

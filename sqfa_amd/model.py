@@ -129,10 +129,11 @@ class SecondMomentsSQFA(nn.Module):
     # the whole closure as ONE autograd node (8 / 11 launches instead of ~40): _native.FusedClosure
     SINGLE_NODE_CLOSURE = True
 
-    def _single_node_inputs(self, prepared):
+    def _single_node_inputs(self, prepared, allow_class_shard=False):
         """(raw parameter, scatters, means, sphere?) when the closure can run as one node: a single
-        Sphere or Identity parametrization on the filters, no class sharding, supported shapes."""
-        if not self.SINGLE_NODE_CLOSURE or self.class_shard is not None:
+        Sphere or Identity parametrization on the filters, supported shapes; class-sharded statistics
+        only for the fitting loop's staged (graph) closure, which places the collectives itself."""
+        if not self.SINGLE_NODE_CLOSURE or (self.class_shard is not None and not allow_class_shard):
             return None
         plist = getattr(getattr(self, "parametrizations", None), "filters", None)
         if plist is None or len(plist) != 1 or type(plist[0]) not in (Sphere, Identity):

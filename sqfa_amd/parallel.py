@@ -56,9 +56,7 @@ class _GatherClasses(torch.autograd.Function):
     @staticmethod
     def forward(ctx, S_local, shard):
         ctx.shard = shard
-        parts = [S_local.new_empty((n,) + tuple(S_local.shape[1:])) for n in shard.counts]
-        dist.all_gather(parts, S_local.contiguous(), group=shard.group)
-        return torch.cat(parts, dim=0)
+        return shard.gather_tensors(S_local)
 
     @staticmethod
     def backward(ctx, g_full):
@@ -86,6 +84,22 @@ class ClassShard:
         self.counts = counts
         self.offset = sum(counts[: self.rank])
         self.n_classes = sum(counts)
+
+    def gather_tensors(self, S_local, recv=None):
+        """All ranks' class slices concatenated along dim 0.  Shards may be uneven: every rank sends a
+        slice padded to the largest shard (all_gather with equal sizes works on RCCL and gloo alike)."""
+        n_max = max(self.counts)
+        send = S_local.contiguous()
+        if send.shape[0] != n_max:
+            padded = send.new_zeros((n_max,) + tuple(send.shape[1:]))
+            padded[: send.shape[0]] = send
+            send = padded
+        if recv is None:
+            recv = send.new_empty((self.world_size,) + tuple(send.shape))
+        dist.all_gather([recv[r] for r in range(self.world_size)], send, group=self.group)
+        if all(n == n_max for n in self.counts):
+            return recv.reshape((self.n_classes,) + tuple(send.shape[1:]))
+        return torch.cat([recv[r, :n] for r, n in enumerate(self.counts)], dim=0)
 
     def gather(self, S_local):
         if S_local.shape[0] != self.counts[self.rank]:

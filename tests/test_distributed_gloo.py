@@ -41,9 +41,9 @@ def _worker(rank, world, port, q):
         model.fit_pca(data_statistics=stats)
         model.pair_shard = shard
         fl, _ = model.fit(data_statistics=stats, max_epochs=3, show_progress=False, return_loss=True)
-        # class-sharded projection: each rank holds 10 of the 20 classes
+        # class-sharded projection: UNEVEN shards (8 and 12 of the 20 classes: slices are padded for the all-gather)
         from sqfa_amd.parallel import ClassShard
-        lo, hi = (0, 10) if rank == 0 else (10, 20)
+        lo, hi = (0, 8) if rank == 0 else (8, 20)
         local = {k: v[lo:hi].clone() for k, v in stats.items()}
         model2 = mc.make_model("sqfa", 50, 2, 1e-3, "sphere", torch.float64, "cpu")
         model2.pair_shard = shard

@@ -159,14 +159,22 @@ def _split_graph_worker(rank, world, port, q):
         torch.cuda.CUDAGraph.replay = replay
         torch.Tensor.cpu = cpu
         runs = {}
-        for name, use_graph, sharded in (("eager", False, True), ("split", True, True), ("single", True, False)):
+        from sqfa_amd.parallel import ClassShard
+        lo, hi = (0, 10) if rank == 0 else (10, 24)          # uneven class shards
+        local = {k: v[lo:hi].contiguous() for k, v in stats.items()}
+        for name, use_graph, sharded, class_sharded in (("eager", False, True, False), ("split", True, True, False),
+                                                        ("single", True, False, False), ("eager_cs", False, True, True),
+                                                        ("split_cs", True, True, True)):
             opt.GRAPH_CLOSURE = use_graph
             model = mc.make_model("sqfa", 96, 4, 0.01, "sphere", torch.float64, dev)
-            model.fit_pca(data_statistics=stats)
             if sharded:
                 model.pair_shard = PairShard()
+            if class_sharded:
+                model.class_shard = ClassShard(hi - lo)
+            data = local if class_sharded else stats
+            model.fit_pca(data_statistics=data)
             counts["replay"] = counts["cpu"] = 0
-            loss, _ = model.fit(data_statistics=stats, max_epochs=6, show_progress=False, return_loss=True)
+            loss, _ = model.fit(data_statistics=data, max_epochs=6, show_progress=False, return_loss=True)
             runs[name] = (loss.numpy(), original_cpu(model.filters.detach()).numpy(), dict(counts))
         q.put((rank, runs))
     finally:
@@ -190,7 +198,7 @@ def test_sharded_closure_runs_as_two_graphs_around_one_all_reduce():
         p.join(timeout=60)
         assert p.exitcode == 0
     (_, r0), (_, r1) = results
-    for name in ("eager", "split", "single"):
+    for name in ("eager", "split", "single", "eager_cs", "split_cs"):
         assert np.array_equal(r0[name][0], r1[name][0]) and np.array_equal(r0[name][1], r1[name][1])   # ranks agree bitwise
     le, Fe, ce = r0["eager"]
     ls, Fs, cs = r0["split"]
@@ -201,6 +209,13 @@ def test_sharded_closure_runs_as_two_graphs_around_one_all_reduce():
     assert cs["cpu"] <= closures + 2, (cs, closures)      # one read-back per closure
     assert np.abs(ls - le).max() < 1e-12 and np.linalg.norm(Fs - Fe) < 1e-10 * np.linalg.norm(Fe)
     assert np.abs(ls - l1).max() < 1e-9 and np.linalg.norm(Fs - F1) < 1e-8 * np.linalg.norm(F1)
+    # class-sharded statistics (uneven shards): four graphs around all-gather, all-reduce, gradient all-reduce
+    lce, Fce, cce = r0["eager_cs"]
+    lcs, Fcs, ccs = r0["split_cs"]
+    assert cce["replay"] == 0 and ccs["replay"] > 80
+    assert ccs["cpu"] <= ccs["replay"] // 4 + 3 + 2
+    assert np.abs(lcs - lce).max() < 1e-11 and np.linalg.norm(Fcs - Fce) < 1e-9 * np.linalg.norm(Fce)
+    assert np.abs(lcs - l1).max() < 1e-9 and np.linalg.norm(Fcs - F1) < 1e-8 * np.linalg.norm(F1)
 
 
 @pytest.mark.timeout(600)
