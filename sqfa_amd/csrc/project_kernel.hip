@@ -81,7 +81,11 @@ __global__ __launch_bounds__(64 * WAVES) void project_kernel(const T* __restrict
       for (int s = 0; s < KC / 4; ++s) {
         int k = kbase + 4 * s + q;
         if (k > D - 1) k = D - 1;  // past the end: F is zero there, any finite row will do
+#ifdef SQFA_PROJ_PLAIN_LOADS
+        const Vec b = *reinterpret_cast<const Vec*>(pc + (size_t)k * D);
+#else
         const Vec b = __builtin_nontemporal_load(reinterpret_cast<const Vec*>(pc + (size_t)k * D));
+#endif
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           const T a = s_f[buf][4 * s + q][nb * 16 + r16];
