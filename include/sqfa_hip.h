@@ -64,7 +64,7 @@ int sqfa_airm_tiling(int nA, int nB, int m, int dtype,
 /* Bytes of device workspace sqfa_airm_pairwise needs for this problem with ANY shard_count (0 on error). */
 size_t sqfa_airm_workspace_bytes(int nA, int nB, int m, int dtype);
 /* The same for calls with this shard_count only (the tile width, hence the slab, depends on it):
- * at C=1000, m=16 103 MB for shard_count 1 instead of the 171 MB bound above. */
+ * at C=1000, m=16 55 MB for shard_count 1 (the slab holds exactly the tiles a shard owns) instead of the bound above. */
 size_t sqfa_airm_workspace_bytes_sharded(int nA, int nB, int m, int dtype, int shard_count);
 
 /*

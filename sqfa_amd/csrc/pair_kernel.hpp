@@ -45,9 +45,11 @@ struct PairParams {
   const void* W;      // optional (nA,nB) pair weights, or nullptr
   const void* EW;     // optional (nA,nB,m) per-eigenvalue weights in eig_out's (unsorted column) order, or nullptr:
                       // the gradient is then that of  sum_ijk EW_ijk lambda_k(A_i,B_j)  (backward of generalized_eigenvalues)
-  void* slab_grad;    // [nbi*nbj][TI+tj][TRI]  lower triangles: TI A-side rows, then tj B-side rows per tile
-  void* slab_loss;    // [nbi*nbj]
-  int* slab_flag;     // [nbi*nbj][2]  {NaN count, inf count}
+  void* slab_grad;    // [tiles of this shard][TI+tj][TRI]  lower triangles: TI A-side rows, then tj B-side rows per tile;
+                      // tiles are numbered like the compact launch grid (row-major over the owned tiles)
+  void* slab_loss;    // [tiles of this shard]
+  int* slab_flag;     // [tiles of this shard][2]  {NaN count, inf count}
+  int* row_start;     // [nbi + 1] number of owned tiles before block-row bi (written by the Cholesky prologue, read by K2)
   void* dist_out;     // (nA,nB) or nullptr
   void* eig_out;      // (nA,nB,m) or nullptr
   unsigned long long* sweep_counter;  // optional debug counter {sum of sweeps, wave rounds}
@@ -741,7 +743,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave id in an SGPR
-  const int tile = bi * p.nbj + bj;
+  const int tile = blockIdx.x;  // compact tile number = slab slot
 
   if (p.want_grad) {
     for (int k = tid; k < WAVES * TI * TRIP; k += NT) s_ga[k] = T(0);

@@ -66,7 +66,7 @@ namespace sqfa {
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct WorkspaceLayout {
-  size_t off_lt, off_linv, off_slab, off_loss, off_flag, total;
+  size_t off_lt, off_linv, off_slab, off_loss, off_flag, off_rows, total;
 };
 
 // Tiles of a shard for tile width tj (same enumeration as the kernel's compact grid).
@@ -114,7 +114,8 @@ static int choose_tile_width(int nA, int nBeff, const Geometry& g, int self_mode
 
 // Workspace for one tiling (only_tj > 0: exactly the tile width a call will use), or for the narrowest
 // tiles any call may choose (only_tj == 0: most tiles, largest slab).
-static WorkspaceLayout layout(int nA, int nBeff, const Geometry& g, size_t esz, int self_mode, int only_tj = 0) {
+static WorkspaceLayout layout(int nA, int nBeff, const Geometry& g, size_t esz, int self_mode, int only_tj = 0,
+                              int shard_count = 1) {
   WorkspaceLayout w;
   const size_t mat = (size_t)g.MR * g.MR * esz;
   const size_t tri = (size_t)g.MR * (g.MR + 1) / 2;
@@ -125,9 +126,12 @@ static WorkspaceLayout layout(int nA, int nBeff, const Geometry& g, size_t esz, 
       if (tj % 2) break;
       continue;
     }
-    const size_t nbj = (nBeff + tj - 1) / tj;
-    slab = std::max(slab, nbi * nbj * (size_t)(g.TI + tj) * tri * esz);
-    tiles = std::max(tiles, nbi * nbj);
+    // the slab holds the tiles one shard owns (compact numbering): the largest shard decides
+    size_t owned = 0;
+    for (int r = 0; r < shard_count; ++r)
+      owned = std::max(owned, (size_t)shard_tiles(nA, nBeff, g, tj, self_mode, r, shard_count));
+    slab = std::max(slab, owned * (size_t)(g.TI + tj) * tri * esz);
+    tiles = std::max(tiles, owned);
     if (tj % 2) break;
   }
   size_t o = 0;
@@ -136,6 +140,7 @@ static WorkspaceLayout layout(int nA, int nBeff, const Geometry& g, size_t esz, 
   w.off_slab = o; o = align_up(o + slab);
   w.off_loss = o; o = align_up(o + tiles * esz);
   w.off_flag = o; o = align_up(o + tiles * 2 * sizeof(int));
+  w.off_rows = o; o = align_up(o + (nbi + 1) * sizeof(int));
   w.total = o;
   return w;
 }
@@ -160,7 +165,18 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 
 template <typename T, int MAXM>
 __global__ __launch_bounds__(256) void cholesky_kernel(const T* __restrict__ S, int m, int MR,
-                                                       T* __restrict__ LT, T* __restrict__ Linv) {
+                                                       T* __restrict__ LT, T* __restrict__ Linv,
+                                                       int* __restrict__ row_start, PairParams pp, int TI) {
+  if (row_start != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    // slab slot table for K2: owned tiles before each block-row, in the compact grid's order
+    int acc = 0;
+    for (int bi = 0; bi < pp.nbi; ++bi) {
+      int first;
+      row_start[bi] = acc;
+      acc += shard_tiles_in_row(bi, tiles_in_row(bi, pp.nbj, TI, pp.tj, pp.self_mode), pp.shard_index, pp.shard_count, &first);
+    }
+    row_start[pp.nbi] = acc;
+  }
   // LDS sized for the padded size class (MAXM >= m) so that small problems keep many
   // workgroups per CU resident
   __shared__ double a[MAXM][MAXM + 1];
@@ -272,11 +288,15 @@ __global__ __launch_bounds__(SQFA_K2_THREADS) void finalize_kernel(const PairPar
       T acc = T(0);
       for (int q = grp; q < n_a + n_b; q += NG) {
         if (q < n_a) {
-          const int bj = first_a + q * N;
-          acc += slab[(size_t)(bi_a * p.nbj + bj) * tile_stride + (size_t)pi * TRI + idx];
+          // the q-th owned tile of block-row bi_a (bj = first_a + q N)
+          acc += slab[(size_t)(p.row_start[bi_a] + q) * tile_stride + (size_t)pi * TRI + idx];
         } else {
           const int bi = first_b + (q - n_a) * N;
-          if (tile_processed(p, bi, bj_b, TI, TJ)) acc += slab[(size_t)(bi * p.nbj + bj_b) * tile_stride + (size_t)(TI + pj) * TRI + idx];
+          if (tile_processed(p, bi, bj_b, TI, TJ)) {
+            const int first_in_row = ((p.shard_index - bi) % N + N) % N;
+            const int slot = p.row_start[bi] + (bj_b - first_in_row) / N;
+            acc += slab[(size_t)slot * tile_stride + (size_t)(TI + pj) * TRI + idx];
+          }
         }
       }
       s_part[grp * 600 + idx] = acc;
@@ -301,14 +321,11 @@ __global__ __launch_bounds__(SQFA_K2_THREADS) void finalize_kernel(const PairPar
   __shared__ int s_f2[SQFA_K2_THREADS];
   double l = 0.0;
   int f = 0, f2 = 0;
-  const int ntiles = p.nbi * p.nbj;
+  const int ntiles = p.row_start[p.nbi];   // every slab slot belongs to a tile this shard processed
   for (int tix = tid; tix < ntiles; tix += SQFA_K2_THREADS) {
-    const int bi = tix / p.nbj, bj = tix % p.nbj;
-    if (tile_processed(p, bi, bj, TI, TJ)) {
-      l += (double)static_cast<const T*>(p.slab_loss)[tix];
-      f += p.slab_flag[2 * tix];
-      f2 += p.slab_flag[2 * tix + 1];
-    }
+    l += (double)static_cast<const T*>(p.slab_loss)[tix];
+    f += p.slab_flag[2 * tix];
+    f2 += p.slab_flag[2 * tix + 1];
   }
   s_l[tid] = l;
   s_f[tid] = f;
@@ -454,7 +471,7 @@ static int pairwise_impl(const void* A, int nA, const void* B, int nB, int m, in
   // tiling (tile ownership (bi + bj) % shard_count is defined on that tiling).
   const int tj = choose_tile_width(nA, nBeff, g, self_mode ? 1 : 0, shard_count);
   const int nbi = (nA + g.TI - 1) / g.TI, nbj = (nBeff + tj - 1) / tj;
-  const WorkspaceLayout w = layout(nA, nBeff, g, esz, self_mode ? 1 : 0, tj);
+  const WorkspaceLayout w = layout(nA, nBeff, g, esz, self_mode ? 1 : 0, tj, shard_count);
   if (workspace_bytes < w.total) return fail(SQFA_ERR_WORKSPACE, "workspace too small", hipSuccess);
   char* ws = static_cast<char*>(workspace);
 
@@ -467,6 +484,7 @@ static int pairwise_impl(const void* A, int nA, const void* B, int nB, int m, in
   p.slab_grad = ws + w.off_slab;
   p.slab_loss = ws + w.off_loss;
   p.slab_flag = reinterpret_cast<int*>(ws + w.off_flag);
+  p.row_start = reinterpret_cast<int*>(ws + w.off_rows);
   p.dist_out = dist_out;
   p.eig_out = eig_out;
   p.sweep_counter = g_sweep_counter;
@@ -489,14 +507,17 @@ static int pairwise_impl(const void* A, int nA, const void* B, int nB, int m, in
   p.uniform_weight_f = (float)uniform_weight;
 
   // K0: factors
+  bool rows_done = false;
   auto launch_chol = [&](auto zero, const void* src, int n, void* lt, void* li) {
     using T = decltype(zero);
     const T* sp = static_cast<const T*>(src);
     T* ltp = static_cast<T*>(lt);
     T* lip = static_cast<T*>(li);
-    if (m <= 16) hipLaunchKernelGGL((cholesky_kernel<T, 16>), dim3(n), dim3(256), 0, stream, sp, m, g.MR, ltp, lip);
-    else if (m <= 32) hipLaunchKernelGGL((cholesky_kernel<T, 32>), dim3(n), dim3(256), 0, stream, sp, m, g.MR, ltp, lip);
-    else hipLaunchKernelGGL((cholesky_kernel<T, 64>), dim3(n), dim3(256), 0, stream, sp, m, g.MR, ltp, lip);
+    int* rows = rows_done ? nullptr : p.row_start;  // the first prologue launch also writes the slab slot table
+    rows_done = true;
+    if (m <= 16) hipLaunchKernelGGL((cholesky_kernel<T, 16>), dim3(n), dim3(256), 0, stream, sp, m, g.MR, ltp, lip, rows, p, g.TI);
+    else if (m <= 32) hipLaunchKernelGGL((cholesky_kernel<T, 32>), dim3(n), dim3(256), 0, stream, sp, m, g.MR, ltp, lip, rows, p, g.TI);
+    else hipLaunchKernelGGL((cholesky_kernel<T, 64>), dim3(n), dim3(256), 0, stream, sp, m, g.MR, ltp, lip, rows, p, g.TI);
   };
   void* ws_lt = ws + w.off_lt;
   void* ws_li = ws + w.off_linv;
@@ -561,7 +582,7 @@ size_t sqfa_airm_workspace_bytes_sharded(int nA, int nB, int m, int dtype, int s
   find_geometry(m, dtype, &g);
   const int nBeff = nB == 0 ? nA : nB, self_mode = nB == 0 ? 1 : 0;
   return layout(nA, nBeff, g, dtype == SQFA_F32 ? 4 : 8, self_mode,
-                choose_tile_width(nA, nBeff, g, self_mode, shard_count)).total;
+                choose_tile_width(nA, nBeff, g, self_mode, shard_count), shard_count).total;
 }
 
 int sqfa_airm_pairwise(const void* A, int nA, const void* B, int nB, int m, int dtype, double scale,
