@@ -167,15 +167,32 @@ template <typename T, int MAXM>
 __global__ __launch_bounds__(256) void cholesky_kernel(const T* __restrict__ S, int m, int MR,
                                                        T* __restrict__ LT, T* __restrict__ Linv,
                                                        int* __restrict__ row_start, PairParams pp, int TI) {
-  if (row_start != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
-    // slab slot table for K2: owned tiles before each block-row, in the compact grid's order
-    int acc = 0;
-    for (int bi = 0; bi < pp.nbi; ++bi) {
-      int first;
-      row_start[bi] = acc;
-      acc += shard_tiles_in_row(bi, tiles_in_row(bi, pp.nbj, TI, pp.tj, pp.self_mode), pp.shard_index, pp.shard_count, &first);
+  if (row_start != nullptr && blockIdx.x == 0) {
+    // slab slot table for K2: owned tiles before each block-row, in the compact grid's order.  The per-row
+    // counts (integer divisions) are evaluated by 256 threads at once, thread 0 only adds them up: a serial
+    // loop here put 9 us on the critical path of the whole prologue (block 0 finished last).
+    __shared__ int s_cnt[256];
+    int base = 0;
+    for (int b0 = 0; b0 < pp.nbi; b0 += 256) {
+      const int bi = b0 + (int)threadIdx.x;
+      int cnt = 0, first;
+      if (bi < pp.nbi)
+        cnt = shard_tiles_in_row(bi, tiles_in_row(bi, pp.nbj, TI, pp.tj, pp.self_mode), pp.shard_index, pp.shard_count, &first);
+      s_cnt[threadIdx.x] = cnt;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int acc = base;
+        for (int k = 0; k < 256 && b0 + k < pp.nbi; ++k) {
+          row_start[b0 + k] = acc;
+          acc += s_cnt[k];
+        }
+        s_cnt[0] = acc;
+      }
+      __syncthreads();
+      base = s_cnt[0];
+      __syncthreads();
     }
-    row_start[pp.nbi] = acc;
+    if (threadIdx.x == 0) row_start[pp.nbi] = base;
   }
   // LDS sized for the padded size class (MAXM >= m) so that small problems keep many
   // workgroups per CU resident
@@ -259,19 +276,35 @@ __global__ __launch_bounds__(SQFA_K2_THREADS) void finalize_kernel(const PairPar
   const int TRI = MR * (MR + 1) / 2;
   const int n_cls = p.nA + (p.self_mode ? 0 : p.nB);
   const int b = blockIdx.x;
-  __shared__ T s_part[8 * 600];
-  if (b < n_cls) {
+  __shared__ T s_part[SQFA_K2_THREADS];
+  // slab slot table (written by the Cholesky prologue) staged in LDS: read from global memory inside the
+  // summation loops it put a second dependent L2 round trip in front of every slab load
+  constexpr int ROWS_LDS = 2048;
+  __shared__ int s_rows[ROWS_LDS];
+  const bool rows_staged = p.nbi + 1 <= ROWS_LDS;
+  if (rows_staged) {
+    for (int k = tid; k <= p.nbi; k += SQFA_K2_THREADS) s_rows[k] = p.row_start[k];
+  }
+  __syncthreads();
+  auto row_start_of = [&](int bi) { return rows_staged ? s_rows[bi] : p.row_start[bi]; };
+  // K2 geometry: a class is split over BPC workgroups of EPB consecutive lower-triangle entries each; inside a
+  // workgroup NG = THREADS / EPB thread groups each sum every NG-th contributing tile (a fixed subsequence),
+  // then the NG partial sums are combined in group order: short dependent chains, bitwise reproducible.
+  // (One workgroup per class with THREADS / TRI groups left m >= 32 -- 528 entries -- with ONE group walking
+  // ~190 tiles serially: 275 us at C=1000, m=32.)
+  // Small sizes (TRI <= 256, m <= 22) keep one workgroup per class (splitting 136 entries over two
+  // workgroups cost 41 vs 30 us at m=16); m=32: 289 -> 199 us.
+  const int EPB = TRI <= 256 ? TRI : 128, NG = SQFA_K2_THREADS / EPB;
+  const int BPC = (TRI + EPB - 1) / EPB;
+  if (b < n_cls * BPC) {
     if (!p.want_grad) return;
-    const bool a_side = b < p.nA;
-    const int c = a_side ? b : b - p.nA;
+    const int cls = b / BPC, e_in = tid % EPB, idx = (b % BPC) * EPB + e_in, grp = tid / EPB;
+    const bool a_side = cls < p.nA;
+    const int c = a_side ? cls : cls - p.nA;
     T* out = a_side ? gradA : gradB;
     if (out == nullptr) return;
     const T* slab = static_cast<const T*>(p.slab_grad);
     const size_t tile_stride = (size_t)(TI + TJ) * TRI;
-    // NG thread groups each sum every NG-th contributing tile (a fixed subsequence), then the
-    // NG partial sums are combined in group order: short dependent chains, bitwise reproducible.
-    int NG = SQFA_K2_THREADS / TRI;
-    NG = NG < 1 ? 1 : (NG > 8 ? 8 : NG);
     const int bi_a = c / TI, pi = c % TI, bj_b = c / TJ, pj = c % TJ;
     // Only the tiles this shard owns are visited (same enumeration as the pair kernel's grid):
     //   as A class: tiles (bi_a, first_a + k N), k < n_a   (row bi_a; self mode: up to the diagonal)
@@ -283,34 +316,36 @@ __global__ __launch_bounds__(SQFA_K2_THREADS) void finalize_kernel(const PairPar
       first_b = ((p.shard_index - bj_b) % N + N) % N;
       n_b = p.nbi > first_b ? (p.nbi - 1 - first_b) / N + 1 : 0;
     }
-    for (int e = tid; e < NG * TRI; e += SQFA_K2_THREADS) {
-      const int grp = e / TRI, idx = e % TRI;
-      T acc = T(0);
+    T acc = T(0);
+    if (idx < TRI && grp < NG) {
       for (int q = grp; q < n_a + n_b; q += NG) {
         if (q < n_a) {
           // the q-th owned tile of block-row bi_a (bj = first_a + q N)
-          acc += slab[(size_t)(p.row_start[bi_a] + q) * tile_stride + (size_t)pi * TRI + idx];
+          acc += slab[(size_t)(row_start_of(bi_a) + q) * tile_stride + (size_t)pi * TRI + idx];
         } else {
           const int bi = first_b + (q - n_a) * N;
           if (tile_processed(p, bi, bj_b, TI, TJ)) {
-            const int first_in_row = ((p.shard_index - bi) % N + N) % N;
-            const int slot = p.row_start[bi] + (bj_b - first_in_row) / N;
+            int slot = row_start_of(bi) + bj_b;  // single shard: every tile of the row is owned
+            if (N > 1) {
+              const int first_in_row = ((p.shard_index - bi) % N + N) % N;
+              slot = row_start_of(bi) + (bj_b - first_in_row) / N;
+            }
             acc += slab[(size_t)slot * tile_stride + (size_t)(TI + pj) * TRI + idx];
           }
         }
       }
-      s_part[grp * 600 + idx] = acc;
     }
+    s_part[tid] = acc;   // [grp][entry]: tid = grp * EPB + e_in
     __syncthreads();
-    for (int idx = tid; idx < TRI; idx += SQFA_K2_THREADS) {
-      T acc = T(0);
-      for (int g2 = 0; g2 < NG; ++g2) acc += s_part[g2 * 600 + idx];
+    if (grp == 0 && idx < TRI) {
+      T tot = T(0);
+      for (int g2 = 0; g2 < NG; ++g2) tot += s_part[g2 * EPB + e_in];
       int r = 0;
       while ((r + 1) * (r + 2) / 2 <= idx) ++r;
       const int cc = idx - r * (r + 1) / 2;
       if (r < p.m && cc < p.m) {
-        out[(size_t)c * p.m * p.m + (size_t)r * p.m + cc] = acc;
-        out[(size_t)c * p.m * p.m + (size_t)cc * p.m + r] = acc;
+        out[(size_t)c * p.m * p.m + (size_t)r * p.m + cc] = tot;
+        out[(size_t)c * p.m * p.m + (size_t)cc * p.m + r] = tot;
       }
     }
     return;
@@ -321,7 +356,7 @@ __global__ __launch_bounds__(SQFA_K2_THREADS) void finalize_kernel(const PairPar
   __shared__ int s_f2[SQFA_K2_THREADS];
   double l = 0.0;
   int f = 0, f2 = 0;
-  const int ntiles = p.row_start[p.nbi];   // every slab slot belongs to a tile this shard processed
+  const int ntiles = row_start_of(p.nbi);   // every slab slot belongs to a tile this shard processed
   for (int tix = tid; tix < ntiles; tix += SQFA_K2_THREADS) {
     l += (double)static_cast<const T*>(p.slab_loss)[tix];
     f += p.slab_flag[2 * tix];
@@ -561,12 +596,14 @@ static int pairwise_impl(const void* A, int nA, const void* B, int nB, int m, in
 
   // K2: slab reduction
   const int n_cls = nA + (self_mode ? 0 : nB);
+  const int k2_tri = g.MR * (g.MR + 1) / 2;
+  const int k2_bpc = k2_tri <= 256 ? 1 : (k2_tri + 127) / 128;  // workgroups per class (finalize_kernel's EPB)
   if (dtype == SQFA_F32) {
-    hipLaunchKernelGGL(finalize_kernel<float>, dim3(n_cls + 1), dim3(SQFA_K2_THREADS), 0, stream, p, g.TI, tj, g.MR,
+    hipLaunchKernelGGL(finalize_kernel<float>, dim3(n_cls * k2_bpc + 1), dim3(SQFA_K2_THREADS), 0, stream, p, g.TI, tj, g.MR,
                        static_cast<float*>(gradA_out), static_cast<float*>(gradB_out),
                        static_cast<float*>(loss_out), nonfinite_out);
   } else {
-    hipLaunchKernelGGL(finalize_kernel<double>, dim3(n_cls + 1), dim3(SQFA_K2_THREADS), 0, stream, p, g.TI, tj, g.MR,
+    hipLaunchKernelGGL(finalize_kernel<double>, dim3(n_cls * k2_bpc + 1), dim3(SQFA_K2_THREADS), 0, stream, p, g.TI, tj, g.MR,
                        static_cast<double*>(gradA_out), static_cast<double*>(gradB_out),
                        static_cast<double*>(loss_out), nonfinite_out);
   }
