@@ -462,7 +462,8 @@ def g7b():
     """c5-shaped configuration (C=100, n_dim=3072, n_filters=16, SQFA, float64, fit_pca init):
     (i) the reference's fit with the Cholesky-route distance_fun (drift of the reference against
     itself under rounding-level differences; compare with G7), (ii) the reference's fit with
-    line_search_fn="strong_wolfe", (iii) the same with the Cholesky-route distance."""
+    line_search_fn="strong_wolfe", (iii) the same with the Cholesky-route distance.  (ii) and (iii) are
+    ~11 000 closures each (~8 CPU-hours on the 8-vCPU build container): only (i) is in the committed file."""
     out = {}
     torch.set_default_dtype(torch.float64)
     stats = c2_statistics(C=100, D=3072)
