@@ -645,6 +645,37 @@ def g3b():
     np.savez_compressed(os.path.join(HERE, "g3b_transform_scatters.npz"), **out)
 
 
+def g6b():
+    """BASELINE config 1 shape (the README example's: 10 classes, n_dim=784, n_filters=4, feature_noise=0.01,
+    SQFA) on the synthetic generator, float64, fit_pca init: the reference's fit, the same with the
+    Cholesky-route distance_fun, and 4 fits from initialisations perturbed by 1e-14 (its own sensitivity)."""
+    out = {}
+    torch.set_default_dtype(torch.float64)
+    stats = c2_statistics(C=10, D=784)
+    out["check_cov00"] = stats["covariances"][0, :4, :4].numpy()
+    rng = np.random.default_rng(6161)
+    model = sqfa.model.SQFA(n_dim=784, n_filters=4, feature_noise=0.01).double()
+    model.fit_pca(data_statistics=stats)
+    out["sqfa_init"] = model.filters.detach().numpy().copy()
+    _fit_record(out, "sqfa", model, stats)
+    model = sqfa.model.SQFA(n_dim=784, n_filters=4, feature_noise=0.01, distance_fun=cholesky_fisher_rao).double()
+    model.fit_pca(data_statistics=stats)
+    _fit_record(out, "sqfa_cholroute", model, stats)
+    ens = []
+    for sample in range(4):
+        model = sqfa.model.SQFA(n_dim=784, n_filters=4, feature_noise=0.01).double()
+        model.fit_pca(data_statistics=stats)
+        with torch.no_grad():
+            prm = model.parametrizations.filters.original
+            prm.mul_(1.0 + 1e-14 * T(rng.standard_normal(tuple(prm.shape)), torch.float64))
+        loss, _ = model.fit(data_statistics=stats, max_epochs=300, show_progress=False, return_loss=True)
+        ens.append(model.filters.detach().numpy())
+        print("c1 perturbed", sample, len(loss), float(loss[-1]), flush=True)
+    out["sqfa_ensemble_filters"] = np.stack(ens)
+    torch.set_default_dtype(torch.float32)
+    np.savez_compressed(os.path.join(HERE, "g6b_fit_c1.npz"), **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g1x", "g2", "g3", "g4", "g5"]
     for name in which:
