@@ -43,6 +43,16 @@ def test_full_fit_filters_match_reference_f64(dname, model_name, K, noise):
     mc.check_fit(dname, model_name, K, noise, 300, DEV, tol_loss=1e-6, tol_filters=1e-5)
 
 
+def _start_from(model, init):
+    """Put the reference's exact initial filters into the raw parameter.  fit_pca here agrees with the
+    reference's to ~2e-14 (host LAPACK, thread-count dependent), which is enough to move the end point of the
+    ill-posed fits (tools/c1_probe.py): trajectory comparisons start from the golden's own initial filters."""
+    init = torch.as_tensor(init, dtype=model.filters.dtype, device=model.filters.device)
+    assert rel_err(model.filters.detach().cpu(), init.cpu()) < 1e-8      # fit_pca itself is checked here
+    with torch.no_grad():
+        model.parametrizations.filters.original.copy_(init)
+
+
 def _reference_drift(golden_b, key_a, golden_a, key_b):
     """Relative distance between two fits of the REFERENCE itself that differ only by rounding:
     its eigh-whitened distance (golden_a) vs the mathematically identical Cholesky-route
@@ -75,6 +85,7 @@ def test_full_fit_flat_orbit_case_f64(model_name):
     stats = mc.fit_stats("syn", torch.float64, DEV)
     model = mc.make_model(model_name, 50, 4, 1e-2, "sphere", torch.float64, DEV)
     model.fit_pca(data_statistics=stats)
+    _start_from(model, mc.G4[f"syn_{model_name}_K4_e300_init"])
     loss, _ = model.fit(data_statistics=stats, max_epochs=300, show_progress=False, return_loss=True)
     key = f"syn_{model_name}_K4_e300"
     ref = mc.G4[f"{key}_loss"]
@@ -127,6 +138,7 @@ def test_strong_wolfe_fit_f64(model_name, pairwise):
     stats = mc.fit_stats("syn", torch.float64, DEV)
     model = mc.make_model(model_name, 50, 4, 1e-2, "sphere", torch.float64, DEV)
     model.fit_pca(data_statistics=stats)
+    _start_from(model, mc.G4[f"syn_{model_name}_K4_e300_init"])
     loss, _ = model.fit(data_statistics=stats, max_epochs=300, show_progress=False, return_loss=True,
                         pairwise=pairwise, line_search_fn="strong_wolfe")
     key = f"syn_{model_name}_{tag}_wolfe"
@@ -224,7 +236,7 @@ def test_c5_config_full_fit_matches_reference_f64():
     stats = {k: v.to(DEV) for k, v in stats.items()}
     model = mc.make_model("sqfa", 3072, 16, 0.01, "sphere", torch.float64, DEV)
     model.fit_pca(data_statistics=stats)
-    assert rel_err(model.filters.detach().cpu(), G7["sqfa_init"]) < 1e-8
+    _start_from(model, G7["sqfa_init"])
     loss, t = model.fit(data_statistics=stats, max_epochs=300, show_progress=False, return_loss=True)
     ref, ref_b = G7["sqfa_loss"], G7B["sqfa_cholroute_loss"]
     drift = rel_err(G7B["sqfa_cholroute_filters"], G7["sqfa_filters"])
@@ -394,9 +406,7 @@ def test_c1_config_full_fit_matches_reference_f64():
     stats = {k: v.to(DEV) for k, v in stats.items()}
     model = mc.make_model("sqfa", 784, 4, 0.01, "sphere", torch.float64, DEV)
     model.fit_pca(data_statistics=stats)
-    assert rel_err(model.filters.detach().cpu(), G["sqfa_init"]) < 1e-9
-    with torch.no_grad():
-        model.parametrizations.filters.original.copy_(torch.tensor(G["sqfa_init"], device=DEV))
+    _start_from(model, G["sqfa_init"])
     loss, t = model.fit(data_statistics=stats, max_epochs=300, show_progress=False, return_loss=True)
     ref = G["sqfa_loss"]
     assert len(loss) == len(ref)
