@@ -81,3 +81,37 @@ def test_cpu_tensors_are_refused():
     S = torch.eye(3).repeat(4, 1, 1)
     with pytest.raises(RuntimeError, match="GPU only"):
         distances.affine_invariant(S, S)
+
+
+def test_argument_validation_of_the_round2_entry_points():
+    """The round-2 entry points reject bad arguments on the host, before any launch (no GPU needed)."""
+    lib = _lib.load()
+    z, fake = ctypes.c_void_p(0), ctypes.c_void_p(4096)
+    # eigenvalue backward: needs weights and an output
+    assert lib.sqfa_airm_eigenvalues_backward(fake, 4, fake, 4, 4, 0, z, fake, fake, fake, 1 << 30, z) == -1
+    assert lib.sqfa_airm_eigenvalues_backward(fake, 4, fake, 4, 4, 0, fake, z, fake, fake, 1 << 30, z) == -1
+    # Gaussian pair terms: null inputs, bad dtype, too large, gradient outputs without upstream gradients
+    assert lib.sqfa_gauss_pair_terms(z, fake, 3, fake, fake, 3, 4, 0, z, z, fake, fake, z, z, z) == -1
+    assert lib.sqfa_gauss_pair_terms(fake, fake, 3, fake, fake, 3, 4, 9, z, z, fake, fake, z, z, z) == -1
+    assert lib.sqfa_gauss_pair_terms(fake, fake, 3, fake, fake, 3, 65, 0, z, z, fake, fake, z, z, z) == -2
+    assert lib.sqfa_gauss_pair_terms(fake, fake, 3, fake, fake, 3, 4, 0, z, z, z, z, fake, fake, z) == -1
+    assert lib.sqfa_gauss_pair_terms(fake, fake, 3, fake, fake, 3, 4, 0, fake, z, z, z, fake, z, z) == -1
+    # closure glue
+    assert lib.sqfa_sphere_forward(z, 4, 8, 0, fake, fake, z) == -1
+    assert lib.sqfa_sphere_forward(fake, 4, 8, 5, fake, fake, z) == -1
+    assert lib.sqfa_sphere_backward(fake, fake, 4, 8, 0, z, 3, z, z, fake, z) == -1          # groups without partial sums
+    assert lib.sqfa_embed_backward_means(fake, z, 3, 4, 0, fake, z) == -1
+    assert lib.sqfa_feature_scatters_ex(fake, 4, 10, fake, 3, 0, 0.0, z, fake, z) == -2       # D % 4 != 0
+    assert lib.sqfa_feature_scatters_backward_ex(fake, 3, fake, 3, 8, 4, 0, 2, fake, z) == -1  # ldg < K
+    assert lib.sqfa_feature_scatters_backward_ex(fake, 6, fake, 3, 8, 6, 0, 2, fake, z) == -2  # K % 4 != 0
+    # L-BFGS
+    assert lib.sqfa_lbfgs_max_history() >= 100
+    assert lib.sqfa_lbfgs_push(fake, fake, fake, 200, 10, 0, fake, fake, 0, z) == -1          # history too long
+    assert lib.sqfa_lbfgs_push(fake, fake, fake, 10, 10, 10, fake, fake, 0, z) == -1          # slot out of range
+    slots = (ctypes.c_int * 2)(0, 11)
+    assert lib.sqfa_lbfgs_direction(fake, fake, fake, 10, 10, slots, 2, fake, z, fake, fake, 0, z) == -1   # bad slot
+    # per-shard workspace: never more than the any-shard bound, and decreasing with the shard's share
+    any_shards = lib.sqfa_airm_workspace_bytes(1000, 0, 16, 0)
+    one, eight = lib.sqfa_airm_workspace_bytes_sharded(1000, 0, 16, 0, 1), lib.sqfa_airm_workspace_bytes_sharded(1000, 0, 16, 0, 8)
+    assert 0 < eight < one <= any_shards and one < 60e6
+    assert lib.sqfa_airm_workspace_bytes_sharded(1000, 0, 16, 0, 0) == 0
