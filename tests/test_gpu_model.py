@@ -239,8 +239,10 @@ def test_c5_config_full_fit_matches_reference_f64():
     _start_from(model, G7["sqfa_init"])
     loss, t = model.fit(data_statistics=stats, max_epochs=300, show_progress=False, return_loss=True)
     ref, ref_b = G7["sqfa_loss"], G7B["sqfa_cholroute_loss"]
-    drift = rel_err(G7B["sqfa_cholroute_filters"], G7["sqfa_filters"])
-    drift_loss = abs(ref_b[-1] - ref[-1])
+    G7C = load_golden("g7c_fit_c5_ensemble.npz")   # two more reference fits, from 1e-14-perturbed initial filters
+    drift = max([rel_err(G7B["sqfa_cholroute_filters"], G7["sqfa_filters"])]
+                + [rel_err(f, G7["sqfa_filters"]) for f in G7C["sqfa_filters"]])       # 2.2e-3, 2.1e-3, 1.7e-4
+    drift_loss = max([abs(ref_b[-1] - ref[-1])] + [abs(v - ref[-1]) for v in G7C["sqfa_final_loss"]])
     F = model.filters.detach().cpu()
     err_a, err_b = rel_err(F, G7["sqfa_filters"]), rel_err(F, G7B["sqfa_cholroute_filters"])
     print(f"c5 sqfa: {len(loss)} epochs (reference {len(ref)}), GPU fit {t[-1].item():.2f} s vs reference CPU "
