@@ -147,7 +147,7 @@ int sqfa_project_scatters(const void *F, int K, int D, const void *Psi, int C, i
  *                                   (G_c + G_c^T) T_c^T  -> partial_out (n_groups,K,D); G (C,K,K) is
  *                                   the gradient wrt S; dL/dF = sum_g P_g (fixed order: reproducible)
  * They replace the einsum of conjugate_matrix (src/sqfa/linalg.py:41) and its autograd backward.
- * float32 or float64, K <= 64; forward needs D % 4 == 0, backward K % 4 == 0
+ * float32 or float64, K <= 64; forward needs D % 4 == 0
  * (SQFA_ERR_UNSUPPORTED_M otherwise: the caller keeps its own expression).
  */
 int sqfa_feature_scatters(const void *F, int K, int D, const void *T, int C, int dtype, void *S_out, void *stream);

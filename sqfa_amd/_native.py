@@ -358,7 +358,7 @@ class ProjectScatters(torch.autograd.Function):
     def backward(ctx, gS):
         (T,) = ctx.saved_tensors
         C, D, K = T.shape
-        if K % 4 == 0 and C >= ProjectScatters.NATIVE_PRODUCTS_MIN_CLASSES:
+        if C >= ProjectScatters.NATIVE_PRODUCTS_MIN_CLASSES:
             lib = _lib.load()
             G = gS.contiguous()
             groups = min(ProjectScatters.BACKWARD_GROUPS, C)
@@ -388,10 +388,10 @@ def project_scatters(scatters, filters):
 
 def fused_closure_supported(raw_filters, scatters, means):
     """Conditions of the single-node closure: the streaming projection's (symmetric (C,D,D) scatters,
-    D % 4 == 0, K <= 64, 16-byte aligned), K % 4 == 0 for the backward product, float32/float64 on
-    the GPU; the means (SQFA) on the same device/dtype."""
+    D % 4 == 0, K <= 64, 16-byte aligned), float32/float64 on the GPU; the means (SQFA) on the same
+    device/dtype."""
     K = raw_filters.shape[0]
-    if not (raw_filters.is_cuda and raw_filters.dim() == 2 and K % 4 == 0 and raw_filters.is_contiguous()):
+    if not (raw_filters.is_cuda and raw_filters.dim() == 2 and raw_filters.is_contiguous()):
         return False
     if means is not None and not (means.is_cuda and means.dtype == scatters.dtype and means.dim() == 2
                                   and not means.requires_grad):

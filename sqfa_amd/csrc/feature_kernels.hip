@@ -113,16 +113,15 @@ __global__ __launch_bounds__(64) void feature_backward_kernel(const T* __restric
     T tv[NB][4], sv[NB][NB][4];
 #pragma unroll
     for (int bc = 0; bc < NB; ++bc) {
-      const int b0 = 16 * bc + 4 * q;  // my four contraction indices b0 .. b0+3 (K % 4 == 0)
+      const int b0 = 16 * bc + 4 * q;  // my four contraction indices b0 .. b0+3 (each guarded: any K)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) tv[bc][e] = (d_ok && b0 < K) ? tc[b0 + e] : T(0);
+      for (int e = 0; e < 4; ++e) tv[bc][e] = (d_ok && b0 + e < K) ? tc[b0 + e] : T(0);
 #pragma unroll
       for (int na = 0; na < NB; ++na) {
         const int a = 16 * na + r16;
-        const bool ok = a < K && b0 < K;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          sv[bc][na][e] = ok ? gc[(size_t)a * ldg + b0 + e] + gc[(size_t)(b0 + e) * ldg + a] : T(0);
+          sv[bc][na][e] = (a < K && b0 + e < K) ? gc[(size_t)a * ldg + b0 + e] + gc[(size_t)(b0 + e) * ldg + a] : T(0);
       }
     }
 #pragma unroll
@@ -197,7 +196,7 @@ extern "C" int sqfa_feature_scatters_backward_ex(const void* G, int ldg, const v
   using namespace sqfa;
   if (G == nullptr || T == nullptr || partial_out == nullptr || !shape_ok(K, D, C, dtype) || n_groups < 1 || ldg < K)
     return SQFA_ERR_BAD_ARGUMENT;
-  if ((K % 4) != 0 || K > 64) return SQFA_ERR_UNSUPPORTED_M;
+  if (K > 64) return SQFA_ERR_UNSUPPORTED_M;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (dtype == SQFA_F32)
     launch_backward(static_cast<const float*>(G), static_cast<const float*>(T), static_cast<float*>(partial_out), C, D, K,

@@ -367,7 +367,8 @@ def test_class_statistics_on_gpu_vs_reference(dtype, tol):
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("constraint", ["sphere", "none"])
 @pytest.mark.parametrize("model_name,C,D,K", [("smsqfa", 24, 96, 4), ("sqfa", 24, 96, 4), ("sqfa", 300, 64, 16),
-                                              ("smsqfa", 7, 132, 32), ("sqfa", 5, 40, 8)])
+                                              ("smsqfa", 7, 132, 32), ("sqfa", 5, 40, 8), ("sqfa", 12, 64, 9),
+                                              ("smsqfa", 300, 96, 2), ("sqfa", 40, 48, 1), ("smsqfa", 9, 72, 17)])
 def test_single_node_closure_matches_autograd_chain(model_name, C, D, K, constraint, dtype):
     """_native.FusedClosure (sphere -> projection -> noise/embedding -> pair loss as ONE autograd node,
     8 / 11 launches) against the chain of autograd nodes it replaces: same loss, flags and gradient
