@@ -365,6 +365,12 @@ __device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
 // fma, five deep) and a wave spends a quarter of its time in s_waitcnt; with two steps in flight the
 // second step's fetch latency hides behind the first step's arithmetic.  Same rotations, same order
 // of the floating-point operations inside every step: results are bitwise identical.
+#ifndef SQFA_FETCH_PRIO
+#define SQFA_FETCH_PRIO 3
+#endif
+#ifndef SQFA_PARAM_PRIO
+#define SQFA_PARAM_PRIO 1
+#endif
 template <typename T, int MR, int CPL, int S, int SWZ, bool LONE_LAST, int C0, int C1, int T_>
 __device__ __forceinline__ void cross_step2(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], int s, T tol2, T tie, bool& big) {
   using R = Real<T>;
@@ -372,11 +378,16 @@ __device__ __forceinline__ void cross_step2(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
   constexpr int cs[2] = {C0, C1 >= 0 ? C1 : C0};
   constexpr int cps[2] = {C0 ^ T_, (C1 >= 0 ? C1 : C0) ^ T_};
   T rv[2][MR];
+  // the fetch bursts are issued at raised priority: the sooner a wave's 2 x MR crossbar requests are in
+  // flight, the more of their latency its SIMD neighbours' arithmetic covers (measured, both bursts at
+  // priority 3: m=16 -2.5 %, m=17 -1 %, m=32 -3.5 %, m=33 -4 %)
+  if (SQFA_FETCH_PRIO) __builtin_amdgcn_s_setprio(SQFA_FETCH_PRIO);
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
 #pragma unroll
     for (int r = 0; r < MR; ++r) rv[q][r] = lane_xor_row<S, SWZ>(x[cps[q]][r], s, r);  // partner's slot cp
   }
+  if (SQFA_FETCH_PRIO) __builtin_amdgcn_s_setprio(0);
   T nr1[2], Dp[2];
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
@@ -389,12 +400,17 @@ __device__ __forceinline__ void cross_step2(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
   for (int q = 0; q < NS; ++q) {
     const int c = cs[q];
     T gh = T(0);
+    // m=16 (four waves per SIMD): the inner product + parameter chain, the latency-critical part of a
+    // step, also runs at raised priority (-1.4 %; +1 % at m=17, no change at m=32: off there)
+    constexpr bool PARAM_PRIO = SQFA_PARAM_PRIO != 0 && MR == 16 && CPL == 4 && sizeof(T) == 4;
+    if (PARAM_PRIO) __builtin_amdgcn_s_setprio(SQFA_PARAM_PRIO);
 #pragma unroll
     for (int r = 0; r < MR; ++r) gh = R::fma_(x[c][r], rv[q][r], gh);
     T u1, k1, g21;
     rot_scaled(nrm[c], nr1[q], gh, D[c], Dp[q], tol2, tie, u1, ru1[q], k1, g21, big);
     kgh[q] = k1 * gh;
     kg2[q] = k1 * g21;
+    if (PARAM_PRIO) __builtin_amdgcn_s_setprio(0);
     const T a = -(kgh[q] * Dp[q]);
 #pragma unroll
     for (int r = 0; r < MR; ++r) x[c][r] = R::fma_(a, rv[q][r], x[c][r]);
@@ -406,6 +422,7 @@ __device__ __forceinline__ void cross_step2(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
     // my slot cp meets the partner's slot c: the partner has just evaluated exactly that rotation
     // from its side (as ITS slot-c rotation); its k is mine with the sign flipped.
     T kgh2[2], kg22[2], ru2[2], Dpn[2];
+    if (SQFA_FETCH_PRIO) __builtin_amdgcn_s_setprio(SQFA_FETCH_PRIO);
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
       kgh2[q] = lane_xor<S>(kgh[q], s);
@@ -415,6 +432,7 @@ __device__ __forceinline__ void cross_step2(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
 #pragma unroll
       for (int r = 0; r < MR; ++r) rv[q][r] = lane_xor_row<S, SWZ>(x[cs[q]][r], s, r);  // partner's slot c, rotated
     }
+    if (SQFA_FETCH_PRIO) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
