@@ -192,14 +192,19 @@ template <int S, typename T> __device__ __forceinline__ T lane_xor(T v, int s) {
 // (tools/ubench/valu_rate.hip), ds_swizzle runs on the otherwise idle LDS crossbar (~2.3
 // cycles per wave-op per CU).  Of every 8 rows, SWZ go through the crossbar so that both
 // pipes share the cross-lane traffic.  Measured optimum (tools/time_variants_any.py): all
-// rows for 4-lane groups; for 8-lane groups, whose partners 4..7 can only be reached through
+// rows for 4-lane groups in round 1 (half of them once the steps were paired, see below); for 8-lane groups, whose partners 4..7 can only be reached through
 // the crossbar anyway, 1 of 8 in float32 and none in float64 (two 32-bit moves per element).
 #ifndef SQFA_SWZ_ROWS_OF_8
 #define SQFA_SWZ_ROWS_OF_8 -1  // -1: by group size and element type
 #endif
-template <typename T, int G> constexpr int swizzled_rows_of_8() {
+template <typename T, int G, int MR> constexpr int swizzled_rows_of_8() {
   if (SQFA_SWZ_ROWS_OF_8 >= 0) return SQFA_SWZ_ROWS_OF_8;
-  return G <= 4 ? 8 : (sizeof(T) == 4 ? 1 : 0);
+  // 4-lane groups: with two steps in flight and the fetch bursts at raised priority (float32, MR >= 16) the
+  // crossbar is the tighter pipe again and half of the rows go back to DPP (round 2, alternating runs on one
+  // box: m=16 1.098 -> 1.066 ms, m=17 1.647 -> 1.588); the unpaired m=12 keeps all rows on the crossbar
+  // (0.574 vs 0.586 ms)
+  if (G <= 4) return (sizeof(T) == 4 && MR >= 16) ? 4 : 8;
+  return sizeof(T) == 4 ? 1 : 0;
 }
 template <int S, int SWZ, typename T> __device__ __forceinline__ T lane_xor_row(T v, int s, int r) {
   if constexpr (S >= 1 && S <= 3 && SWZ > 0) {
@@ -498,9 +503,9 @@ template <typename T, int MR, int G, int CPL, int S>
 __device__ __forceinline__ void cross_rounds_static(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], T tol2, bool& big) {
   if constexpr (S < G) {
     if constexpr (paired_steps<T, G, MR>())
-      cross_round_paired<T, MR, CPL, S, swizzled_rows_of_8<T, G>(), (MR == G * (CPL - 1) + 1)>(x, nrm, D, S, tol2, big);
+      cross_round_paired<T, MR, CPL, S, swizzled_rows_of_8<T, G, MR>(), (MR == G * (CPL - 1) + 1)>(x, nrm, D, S, tol2, big);
     else
-      cross_round<T, MR, CPL, S, swizzled_rows_of_8<T, G>(), (MR == G * (CPL - 1) + 1)>(x, nrm, D, S, tol2, big);
+      cross_round<T, MR, CPL, S, swizzled_rows_of_8<T, G, MR>(), (MR == G * (CPL - 1) + 1)>(x, nrm, D, S, tol2, big);
     cross_rounds_static<T, MR, G, CPL, S + 1>(x, nrm, D, tol2, big);
   }
 }
