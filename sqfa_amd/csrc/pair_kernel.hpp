@@ -833,7 +833,11 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
       for (int k = 0; k <= r; ++k) {
         const T l = li[li_at(r, k)];
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) acc[c] = R::fma_(l, x[c][k], acc[c]);
+        for (int c = 0; c < CPL; ++c) {
+          // slot c holds column c*G + g >= c*G of the lower triangular L_i: its entries k < c*G are zero in
+          // every lane, so those terms (half of them at m=16) are skipped at compile time
+          if (k >= c * G) acc[c] = R::fma_(l, x[c][k], acc[c]);
+        }
       }
 #pragma unroll
       for (int c = 0; c < CPL; ++c) x[c][r] = acc[c];
