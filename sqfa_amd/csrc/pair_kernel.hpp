@@ -301,6 +301,23 @@ __device__ __forceinline__ void rot_scaled(T no, T nr, T gh, T Dx, T Dy, T tol2,
   k = rot ? R::copysign_(T(0.5) * rh * ruu, sgn) : T(0);
 }
 
+// Sizes m = G (CPL-1) + 1 (SQFA's K+1: 17 = 4*4+1, 33 = 8*4+1) leave ONE real column in the last slot of
+// one lane of the group.  Carried through the tournament it doubles the rounds of every partner
+// (pow2ceil(CPL) = 8 instead of 4) for steps in which a single lane pair of the group does useful work.
+// With SQFA_Z_VISITS the tournament runs over the first CPL-1 slots only and the lone column ("z") travels
+// instead: it visits the lanes of its group one after the other along a Gray-code path of xor moves and
+// meets the CPL-1 columns of the lane it is visiting as LOCAL rotations (no partner fetches, no second
+// update); the empty last slots of the other lanes hold zero columns, for which rot_scaled returns the
+// identity.  Every pair of columns still meets exactly once per sweep.
+#ifndef SQFA_Z_VISITS
+#define SQFA_Z_VISITS 1
+#endif
+template <int G, int MR, int CPL> constexpr bool z_visits_cfg() {
+  return SQFA_Z_VISITS && G > 1 && MR == G * (CPL - 1) + 1;
+}
+// slots that take part in the tournaments (LONE_LAST: all but the last)
+template <int CPL, bool LONE_LAST> constexpr int tournament_slots() { return (LONE_LAST && SQFA_Z_VISITS) ? CPL - 1 : CPL; }
+
 // one tournament round against the lane group member (lane ^ s): every column slot c of
 // mine meets slot (c ^ t) of the partner, t = 0..pow2ceil(CPL)-1.
 //
@@ -314,15 +331,16 @@ __device__ __forceinline__ void rot_scaled(T no, T nr, T gh, T Dx, T Dy, T tol2,
 template <typename T, int MR, int CPL, int S, int SWZ, bool LONE_LAST>
 __device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], int s, T tol2, bool& big) {
   using R = Real<T>;
-  constexpr int TP2 = pow2ceil(CPL);
+  constexpr int CE = tournament_slots<CPL, LONE_LAST>();
+  constexpr int TP2 = pow2ceil(CE);
   const int lane_id = (int)(threadIdx.x & 63);
   const T tie = ((lane_id ^ s) > lane_id) ? T(1) : T(-1);
 #pragma unroll
   for (int t = 0; t < TP2; ++t) {
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) {
+    for (int c = 0; c < CE; ++c) {
       const int cp = c ^ t;
-      if (cp < c || cp >= CPL) continue;  // resolved at compile time after unrolling
+      if (cp < c || cp >= CE) continue;  // resolved at compile time after unrolling
       // LONE_LAST: the last slot holds a real column in ONE lane of the group only (MR = G(CPL-1)+1,
       // e.g. 17 = 4*4+1), so no two lanes ever have a last-slot pair to rotate
       if (LONE_LAST && c == CPL - 1 && cp == CPL - 1) continue;
@@ -456,8 +474,9 @@ template <typename T, int MR, int CPL, int S, int SWZ, bool LONE_LAST, int T_, i
 __device__ __forceinline__ void cross_t_steps(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], int s, T tol2, T tie, bool& big) {
   // find the next two valid first slots from CSTART on (compile time)
   constexpr auto valid = [](int c) constexpr {
+    constexpr int CE = tournament_slots<CPL, LONE_LAST>();
     const int cp = c ^ T_;
-    if (c >= CPL || cp < c || cp >= CPL) return false;
+    if (c >= CE || cp < c || cp >= CE) return false;
     if (LONE_LAST && c == CPL - 1 && cp == CPL - 1) return false;
     return true;
   };
@@ -475,7 +494,7 @@ __device__ __forceinline__ void cross_t_steps(T (&x)[CPL][MR], T (&nrm)[CPL], T 
 
 template <typename T, int MR, int CPL, int S, int SWZ, bool LONE_LAST, int T_ = 0>
 __device__ __forceinline__ void cross_round_paired(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], int s, T tol2, bool& big) {
-  constexpr int TP2 = pow2ceil(CPL);
+  constexpr int TP2 = pow2ceil(tournament_slots<CPL, LONE_LAST>());
   if constexpr (T_ < TP2) {
     const int lane_id = (int)(threadIdx.x & 63);
     const T tie = ((lane_id ^ s) > lane_id) ? T(1) : T(-1);
@@ -565,11 +584,36 @@ __device__ __forceinline__ void local_t_steps(T (&x)[CPL][MR], T (&nrm)[CPL], T 
     }
   }
 }
+template <typename T, int MR, int CPL, int C>
+__device__ __forceinline__ void z_visit_steps(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], T tol2, bool& big) {
+  if constexpr (C < CPL - 1) {
+    local_step2<T, MR, CPL, C, CPL - 1, -1, -1>(x, nrm, D, tol2, big);
+    z_visit_steps<T, MR, CPL, C + 1>(x, nrm, D, tol2, big);
+  }
+}
 template <typename T, int MR, int CPL, int T_>
 __device__ __forceinline__ void local_rounds(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], T tol2, bool& big) {
   if constexpr (T_ < pow2ceil(CPL)) {
     local_t_steps<T, MR, CPL, T_, 0>(x, nrm, D, tol2, big);
     local_rounds<T, MR, CPL, T_ + 1>(x, nrm, D, tol2, big);
+  }
+}
+
+// The travelling lone column (see SQFA_Z_VISITS above): visit V rotates the last slot against the other
+// slots of the lane, then every lane takes its partner's last slot.  The moves follow the reflected Gray
+// code (xor 1, 2, 1, 4, 1, 2, 1, ...), the last one (xor G/2) brings the column home.
+template <typename T, int MR, int G, int CPL, int SWZ, int V>
+__device__ __forceinline__ void z_visits(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], T tol2, bool& big) {
+  if constexpr (V < G) {
+    constexpr int Z = CPL - 1;
+    z_visit_steps<T, MR, CPL, 0>(x, nrm, D, tol2, big);
+    constexpr int NXT = V + 1;
+    constexpr int BIT = (NXT == G) ? G / 2 : (NXT & -NXT);
+#pragma unroll
+    for (int r = 0; r < MR; ++r) x[Z][r] = lane_xor_row<BIT, SWZ>(x[Z][r], BIT, r);
+    nrm[Z] = lane_xor<BIT>(nrm[Z], BIT);
+    D[Z] = lane_xor<BIT>(D[Z], BIT);
+    z_visits<T, MR, G, CPL, SWZ, V + 1>(x, nrm, D, tol2, big);
   }
 }
 
@@ -880,10 +924,11 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
       if constexpr (SQFA_LOCAL_TOURNAMENT && G == 1) {  // measured: m=8 (one lane per pair) -4 %; no change for G >= 4
         local_rounds<T, MR, CPL, 1>(x, nrm, D, tol2, big);
       } else {
+      constexpr int CE = z_visits_cfg<G, MR, CPL>() ? CPL - 1 : CPL;  // the lone column meets them in z_visits
 #pragma unroll
-      for (int c1 = 0; c1 < CPL; ++c1) {
+      for (int c1 = 0; c1 < CE; ++c1) {
 #pragma unroll
-        for (int c2 = c1 + 1; c2 < CPL; ++c2) {
+        for (int c2 = c1 + 1; c2 < CE; ++c2) {
           T gh = T(0);
 #pragma unroll
           for (int r = 0; r < MR; ++r) gh = R::fma_(x[c1][r], x[c2][r], gh);
@@ -911,6 +956,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
 #pragma unroll 1
         for (int s = 1; s < G; ++s) cross_round<T, MR, CPL, 0, 0, (MR == G * (CPL - 1) + 1)>(x, nrm, D, s, tol2, big);
       }
+      if constexpr (z_visits_cfg<G, MR, CPL>()) z_visits<T, MR, G, CPL, swizzled_rows_of_8<T, G, MR>(), 0>(x, nrm, D, tol2, big);
       more = __any(big);
       ++sweeps;
     }
