@@ -732,16 +732,22 @@ struct PairCfg {
   static constexpr int MAX_SWEEPS = SQFA_MAX_SWEEPS;
   // lane groups up to this size unroll the tournament rounds (compile-time partners: DPP / ds_swizzle);
   // larger groups loop over the partner at run time (ds_bpermute)
+  // (round 2, C=1000: unrolling the 15 / 31 rounds of the 16- / 32-lane groups as well -- float32 m=48 67.1 -> 43.7 ms,
+  // m=64 178.7 -> 123.6; float64 m=24 29.8 -> 13.1, m=32 43.3 -> 36.5 (with one wave per SIMD), m=33 58.3 -> 51.6;
+  // float64 32-lane groups (m=48) spill out of 512 VGPRs when unrolled, 313 -> 1256 ms: run-time loop kept there)
 #ifndef SQFA_STATIC_G
-#define SQFA_STATIC_G 8
+#define SQFA_STATIC_G 0  // 0: by element type
 #endif
-  static constexpr int STATIC_G = SQFA_STATIC_G;
+  static constexpr int STATIC_G = SQFA_STATIC_G > 0 ? SQFA_STATIC_G : (sizeof(T) == 4 ? 32 : 16);
   // register budget: waves per SIMD the kernel is compiled for (256-thread blocks)
   static constexpr int XREGS = CPL * MR * (int)(sizeof(T) / 4);
 #ifndef SQFA_F64_SMALL_WAVES
 #define SQFA_F64_SMALL_WAVES 3  // 168 VGPRs: measured 8 % faster than 2 waves at m=16 (LDS allows 3 workgroups per CU)
 #endif
-  static constexpr int MIN_WAVES = sizeof(T) == 8 ? (XREGS <= 64 ? SQFA_F64_SMALL_WAVES : (XREGS <= 140 ? 2 : 1))
+  // float64 16-lane groups with their 15 rounds unrolled: m=32 (128 registers of state) needs the whole file
+  // (1261 spilled VGPRs at two waves per SIMD), m=24 (96) fits two waves
+  static constexpr int F64_TWO_WAVE_XREGS = G_ >= 16 ? 100 : 140;
+  static constexpr int MIN_WAVES = sizeof(T) == 8 ? (XREGS <= 64 ? SQFA_F64_SMALL_WAVES : (XREGS <= F64_TWO_WAVE_XREGS ? 2 : 1))
                                                   : (XREGS <= 64 ? 4 : (XREGS <= 100 ? 3 : (XREGS <= 170 ? 2 : 1)));
   // L_j^-1 staged in LDS as a packed lower triangle (one-wave workgroups, m >= 32: 8 instead of 7
   // workgroups per CU) or as a full MR x MR block (smaller sizes: no occupancy to gain, and the
