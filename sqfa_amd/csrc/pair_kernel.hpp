@@ -885,8 +885,11 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
           // slot c holds column c*G + g >= c*G of the lower triangular L_i: its entries k < c*G are zero in
-          // every lane, so those terms (half of them at m=16) are skipped at compile time
-          if (k >= c * G) acc[c] = R::fma_(l, x[c][k], acc[c]);
+          // every lane, so those terms are skipped at compile time (m=32 -1.6 %, m=17 -0.6 %).  Not for the
+          // float32 m=16 instantiation: no time to gain there (1.076 vs 1.078 ms) and the shorter live ranges
+          // make the register allocator spill 7 VGPRs instead of 1 (+30 MB of scratch traffic per launch)
+          constexpr bool SKIP_ZEROS = !(sizeof(T) == 4 && MR == 16);
+          if (!SKIP_ZEROS || k >= c * G) acc[c] = R::fma_(l, x[c][k], acc[c]);
         }
       }
 #pragma unroll
