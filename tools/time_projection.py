@@ -22,4 +22,4 @@ def run(C, D, K, reps=20):
     print(f"C={C} D={D} K={K}: forward {tf:.3f} ms = {byts/tf/1e6:.0f} GB/s ({byts/tf/1e6/8000*100:.0f}% of 8 TB/s), backward {tb:.3f} ms", flush=True)
 
 if __name__ == "__main__":
-    run(1000, 784, 16); run(100, 784, 8); run(300, 2048, 32); run(100, 3072, 16); run(1000, 784, 4); run(400, 1024, 64)
+    run(1000, 784, 16); run(100, 784, 8); run(300, 2048, 32); run(100, 3072, 16); run(1000, 784, 4); run(400, 1024, 64); run(10, 784, 4); run(50, 784, 8); run(200, 784, 16); run(30, 3072, 16)
