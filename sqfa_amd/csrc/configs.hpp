@@ -11,9 +11,11 @@
   X(float, 12, 4, 3, 8, 4)   \
   X(float, 16, 4, 4, 8, 4)  \
   X(float, 17, 4, 5, 8, 4)  \
+  X(float, 20, 4, 5, 8, 4)  \
   X(float, 24, 8, 3, 8, 4)   \
   X(float, 32, 8, 4, 4, 1)   \
   X(float, 33, 8, 5, 4, 1)   \
+  X(float, 40, 8, 5, 4, 1)   \
   X(float, 48, 16, 3, 4, 1)  \
   X(float, 64, 32, 2, 4, 2)
 
@@ -23,6 +25,7 @@
   X(double, 12, 4, 3, 8, 4)  \
   X(double, 16, 8, 2, 8, 4)  \
   X(double, 17, 8, 3, 8, 4)  \
+  X(double, 20, 8, 3, 8, 4)  \
   X(double, 24, 16, 2, 4, 1) \
   X(double, 32, 16, 2, 4, 1) \
   X(double, 33, 16, 3, 4, 1) \

@@ -21,7 +21,7 @@ def spd(rng, n, m):
 
 CASES = []
 _rng = np.random.default_rng(2025)
-for m in (1, 2, 3, 4, 5, 7, 8, 9, 11, 12, 13, 16, 17, 18, 20, 23, 24, 25, 31, 32, 33, 41, 48, 57, 64):
+for m in (1, 2, 3, 4, 5, 7, 8, 9, 11, 12, 13, 16, 17, 18, 20, 23, 24, 25, 31, 32, 33, 36, 40, 41, 48, 57, 64):
     for _ in range(int(os.environ.get("SQFA_FUZZ_ROUNDS", "2"))):  # soak runs: SQFA_FUZZ_ROUNDS=30
         self_mode = bool(_rng.integers(0, 2))
         nA = int(_rng.integers(2, 40 if m <= 17 else 14))
