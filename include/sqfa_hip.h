@@ -163,7 +163,9 @@ int sqfa_feature_scatters_backward(const void *G, const void *T, int C, int D, i
  *                                   [[S + m m^T, m], [m^T, 1]] (src/sqfa/distances.py:141-174) written as
  *                                   (C, K+1, K+1) into S_out
  *   sqfa_feature_scatters_backward_ex  as sqfa_feature_scatters_backward for G stored with row pitch / class
- *                                   size ldg (K, or K+1 to read the top-left block of a gradient wrt the embedding)
+ *                                   size ldg (K, or K+1 to read the top-left block of a gradient wrt the embedding);
+ *                                   g_symmetric != 0: the caller guarantees G_c = G_c^T (true for the gradients
+ *                                   sqfa_airm_pairwise writes), G_c + G_c^T is then read as 2 G_c along rows only
  *   sqfa_embed_backward_means       gm_out (C,K) = (G + G^T) m + gE[:K,K] + gE[K,:K]: gradient wrt the projected means
  *   sqfa_sphere_forward             F = X / ||X||_row, norms_out (K)    (Sphere.forward, src/sqfa/constraints.py:37)
  *   sqfa_sphere_backward            grad_out (K,D) = gloss * (gF - F (F.gF)) / ||X||  with
@@ -174,7 +176,7 @@ int sqfa_feature_scatters_backward(const void *G, const void *T, int C, int D, i
 int sqfa_feature_scatters_ex(const void *F, int K, int D, const void *T, int C, int dtype, double noise,
                              const void *means_f, void *S_out, void *stream);
 int sqfa_feature_scatters_backward_ex(const void *G, int ldg, const void *T, int C, int D, int K, int dtype,
-                                      int n_groups, void *partial_out, void *stream);
+                                      int n_groups, int g_symmetric, void *partial_out, void *stream);
 int sqfa_embed_backward_means(const void *gE, const void *means_f, int C, int K, int dtype, void *gm_out, void *stream);
 int sqfa_sphere_forward(const void *X, int K, int D, int dtype, void *F_out, void *norms_out, void *stream);
 int sqfa_sphere_backward(const void *X, const void *norms, int K, int D, int dtype, const void *partials, int n_groups,

@@ -72,7 +72,7 @@ PROTOTYPES = {
     "sqfa_feature_scatters_backward_ex": (
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-         ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p],
+         ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p],
     ),
     "sqfa_embed_backward_means": (
         ctypes.c_int,

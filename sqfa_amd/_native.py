@@ -314,6 +314,20 @@ def native_projection_supported(scatters, filters):
     )
 
 
+def backward_groups(C, D, cap=64):
+    """Class groups of sqfa_feature_scatters_backward: the kernel wants ~3000 waves in flight (one per 16-column
+    block and group; it is latency-bound), while the (groups, K, D) partial sums are re-read by the reduction that
+    follows, whose time grows with the group count.  Measured (tools/time_feature_backward.py, backward + reduction):
+    c3 (D=784) 64 groups 34 us (16: 43), c4 (D=2048) 32: 128 us (64: 139, 16: 151), c5 (D=3072, C=100) 16: 28 us
+    (64: 56)."""
+    blocks = (D + 15) // 16
+    want = max(1, -(-3072 // blocks))
+    groups = 8
+    while groups < want:
+        groups *= 2
+    return max(1, min(groups, cap, C))
+
+
 class ProjectScatters(torch.autograd.Function):
     """S_c = F Psi_c F^T for symmetric Psi_c, reading Psi (C,D,D) from HBM once.
 
@@ -324,8 +338,7 @@ class ProjectScatters(torch.autograd.Function):
     Replaces conjugate_matrix (reference src/sqfa/linalg.py:19-45) in transform_scatters
     (src/sqfa/model.py:172-188), whose autograd reads Psi a second time in the backward."""
 
-    # class groups of the backward kernel: 64 keeps ~3000 waves in flight at D = 784 (one per
-    # 16-column block and group; the kernel is latency-bound) and the (groups, K, D) partial sums at 3 MB
+    # class groups of the backward kernel (one wave per 16-column block and group): see backward_groups
     BACKWARD_GROUPS = 64
     # S = F T and dL/dF go through the HIP kernels from this many classes on (measured, closure at
     # C=1000, D=784, K=16: 1.61 -> 1.56 ms); below, torch's batched GEMMs are as fast (both are
@@ -361,7 +374,7 @@ class ProjectScatters(torch.autograd.Function):
         if C >= ProjectScatters.NATIVE_PRODUCTS_MIN_CLASSES:
             lib = _lib.load()
             G = gS.contiguous()
-            groups = min(ProjectScatters.BACKWARD_GROUPS, C)
+            groups = backward_groups(C, D, ProjectScatters.BACKWARD_GROUPS)
             with torch.cuda.device(T.device):
                 partial = torch.empty((groups, K, D), dtype=T.dtype, device=T.device)
                 stream = ctypes.c_void_p(torch.cuda.current_stream(T.device).cuda_stream)
@@ -460,13 +473,14 @@ def closure_stage_backward(st, gS, gloss):
     C, D, K = T.shape
     code = _dtype_code(T)
     dev, dt = T.device, T.dtype
-    groups = min(FusedClosure.BACKWARD_GROUPS, C)
+    groups = backward_groups(C, D, FusedClosure.BACKWARD_GROUPS)
     gS = gS.contiguous()
     ldg = gS.shape[-1]
     with torch.cuda.device(dev):
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         partial = torch.empty((groups, K, D), dtype=dt, device=dev)
-        _lib.check(lib.sqfa_feature_scatters_backward_ex(_ptr(gS), ldg, _ptr(T), C, D, K, code, groups, _ptr(partial), stream),
+        # gS is the pair kernels' dL/dS (or dL/dE): written symmetric by sqfa_airm_pairwise, sums of shards included
+        _lib.check(lib.sqfa_feature_scatters_backward_ex(_ptr(gS), ldg, _ptr(T), C, D, K, code, groups, 1, _ptr(partial), stream),
                    "sqfa_feature_scatters_backward_ex")
         extra = None
         if m is not None:

@@ -92,12 +92,18 @@ __global__ __launch_bounds__(64 * NB * SPLIT) void feature_scatters_kernel(const
 //   A[i][k] = sym[16 na + i][16 bc + 4 k + e],  B[k][j] = T_c[d0 + j][16 bc + 4 k + e].
 // Classes are visited in a fixed order and the groups are summed in a fixed order by the
 // caller: bitwise reproducible.
-template <typename T, int NB>
+// TV: K % 4 == 0, a lane's four T elements are one 16-byte load.  SYM: the caller guarantees G_c = G_c^T (the
+// pair kernels' dL/dS is written symmetric), so G_c + G_c^T = 2 G_c read along rows only -- no transposed
+// (uncoalesced) second read; GV: and its rows are 16-byte aligned (ldg % 4 == 0).  The kernel is bound by the
+// number of load instructions per class (round 2, c4 shape: 40 dword loads per class and wave, 365 us for
+// 262 MB of T): 6 with TV+SYM+GV.
+template <typename T, int NB, bool TV, bool SYM, bool GV>
 __global__ __launch_bounds__(64) void feature_backward_kernel(const T* __restrict__ G, const T* __restrict__ Tm,
                                                               T* __restrict__ P, int C, int D, int K, int n_groups,
                                                               int ldg) {
   using Tr = ProjTraits<T>;
   using Acc = typename Tr::Acc;
+  struct alignas(4 * sizeof(T)) Vec4 { T v[4]; };
   const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
   const int d = 16 * blockIdx.x + r16, g = blockIdx.y;
   const bool d_ok = d < D;
@@ -114,14 +120,31 @@ __global__ __launch_bounds__(64) void feature_backward_kernel(const T* __restric
 #pragma unroll
     for (int bc = 0; bc < NB; ++bc) {
       const int b0 = 16 * bc + 4 * q;  // my four contraction indices b0 .. b0+3 (each guarded: any K)
+      if constexpr (TV) {
+        Vec4 t4 = {{T(0), T(0), T(0), T(0)}};
+        if (d_ok && b0 < K) t4 = *reinterpret_cast<const Vec4*>(tc + b0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) tv[bc][e] = (d_ok && b0 + e < K) ? tc[b0 + e] : T(0);
+        for (int e = 0; e < 4; ++e) tv[bc][e] = t4.v[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tv[bc][e] = (d_ok && b0 + e < K) ? tc[b0 + e] : T(0);
+      }
 #pragma unroll
       for (int na = 0; na < NB; ++na) {
         const int a = 16 * na + r16;
+        if constexpr (SYM && GV) {
+          Vec4 g4 = {{T(0), T(0), T(0), T(0)}};
+          if (a < K && b0 < K) g4 = *reinterpret_cast<const Vec4*>(gc + (size_t)a * ldg + b0);  // K % 4 == 0 with GV
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          sv[bc][na][e] = (a < K && b0 + e < K) ? gc[(size_t)a * ldg + b0 + e] + gc[(size_t)(b0 + e) * ldg + a] : T(0);
+          for (int e = 0; e < 4; ++e) sv[bc][na][e] = T(2) * g4.v[e];
+        } else if constexpr (SYM) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sv[bc][na][e] = (a < K && b0 + e < K) ? T(2) * gc[(size_t)a * ldg + b0 + e] : T(0);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            sv[bc][na][e] = (a < K && b0 + e < K) ? gc[(size_t)a * ldg + b0 + e] + gc[(size_t)(b0 + e) * ldg + a] : T(0);
+        }
       }
     }
 #pragma unroll
@@ -153,15 +176,28 @@ static void launch_forward(const T* f, const T* t, T* s, int C, int D, int K, T 
   }
 }
 
-template <typename T>
-static void launch_backward(const T* g, const T* t, T* p, int C, int D, int K, int n_groups, int ldg, hipStream_t stream) {
+template <typename T, bool TV, bool SYM, bool GV>
+static void launch_backward_v(const T* g, const T* t, T* p, int C, int D, int K, int n_groups, int ldg, hipStream_t stream) {
   const dim3 grid((D + 15) / 16, n_groups, 1), block(64);
   switch ((K + 15) / 16) {
-    case 1: hipLaunchKernelGGL((feature_backward_kernel<T, 1>), grid, block, 0, stream, g, t, p, C, D, K, n_groups, ldg); break;
-    case 2: hipLaunchKernelGGL((feature_backward_kernel<T, 2>), grid, block, 0, stream, g, t, p, C, D, K, n_groups, ldg); break;
-    case 3: hipLaunchKernelGGL((feature_backward_kernel<T, 3>), grid, block, 0, stream, g, t, p, C, D, K, n_groups, ldg); break;
-    default: hipLaunchKernelGGL((feature_backward_kernel<T, 4>), grid, block, 0, stream, g, t, p, C, D, K, n_groups, ldg); break;
+    case 1: hipLaunchKernelGGL((feature_backward_kernel<T, 1, TV, SYM, GV>), grid, block, 0, stream, g, t, p, C, D, K, n_groups, ldg); break;
+    case 2: hipLaunchKernelGGL((feature_backward_kernel<T, 2, TV, SYM, GV>), grid, block, 0, stream, g, t, p, C, D, K, n_groups, ldg); break;
+    case 3: hipLaunchKernelGGL((feature_backward_kernel<T, 3, TV, SYM, GV>), grid, block, 0, stream, g, t, p, C, D, K, n_groups, ldg); break;
+    default: hipLaunchKernelGGL((feature_backward_kernel<T, 4, TV, SYM, GV>), grid, block, 0, stream, g, t, p, C, D, K, n_groups, ldg); break;
   }
+}
+
+template <typename T>
+static void launch_backward(const T* g, const T* t, T* p, int C, int D, int K, int n_groups, int ldg, bool symmetric,
+                            hipStream_t stream) {
+  constexpr size_t VB = 4 * sizeof(T);
+  const bool tvec = (K % 4) == 0 && (reinterpret_cast<size_t>(t) % VB) == 0;
+  const bool gvec = symmetric && tvec && (ldg % 4) == 0 && (reinterpret_cast<size_t>(g) % VB) == 0;
+  if (tvec && gvec) launch_backward_v<T, true, true, true>(g, t, p, C, D, K, n_groups, ldg, stream);
+  else if (tvec && symmetric) launch_backward_v<T, true, true, false>(g, t, p, C, D, K, n_groups, ldg, stream);
+  else if (tvec) launch_backward_v<T, true, false, false>(g, t, p, C, D, K, n_groups, ldg, stream);
+  else if (symmetric) launch_backward_v<T, false, true, false>(g, t, p, C, D, K, n_groups, ldg, stream);
+  else launch_backward_v<T, false, false, false>(g, t, p, C, D, K, n_groups, ldg, stream);
 }
 
 static bool shape_ok(int K, int D, int C, int dtype) {
@@ -192,7 +228,7 @@ extern "C" int sqfa_feature_scatters(const void* F, int K, int D, const void* T,
 }
 
 extern "C" int sqfa_feature_scatters_backward_ex(const void* G, int ldg, const void* T, int C, int D, int K, int dtype,
-                                                 int n_groups, void* partial_out, void* stream_) {
+                                                 int n_groups, int g_symmetric, void* partial_out, void* stream_) {
   using namespace sqfa;
   if (G == nullptr || T == nullptr || partial_out == nullptr || !shape_ok(K, D, C, dtype) || n_groups < 1 || ldg < K)
     return SQFA_ERR_BAD_ARGUMENT;
@@ -200,14 +236,14 @@ extern "C" int sqfa_feature_scatters_backward_ex(const void* G, int ldg, const v
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (dtype == SQFA_F32)
     launch_backward(static_cast<const float*>(G), static_cast<const float*>(T), static_cast<float*>(partial_out), C, D, K,
-                    n_groups, ldg, stream);
+                    n_groups, ldg, g_symmetric != 0, stream);
   else
     launch_backward(static_cast<const double*>(G), static_cast<const double*>(T), static_cast<double*>(partial_out), C, D,
-                    K, n_groups, ldg, stream);
+                    K, n_groups, ldg, g_symmetric != 0, stream);
   return hipGetLastError() == hipSuccess ? SQFA_OK : SQFA_ERR_LAUNCH;
 }
 
 extern "C" int sqfa_feature_scatters_backward(const void* G, const void* T, int C, int D, int K, int dtype, int n_groups,
                                               void* partial_out, void* stream_) {
-  return sqfa_feature_scatters_backward_ex(G, K, T, C, D, K, dtype, n_groups, partial_out, stream_);
+  return sqfa_feature_scatters_backward_ex(G, K, T, C, D, K, dtype, n_groups, 0, partial_out, stream_);
 }

@@ -102,8 +102,8 @@ def test_argument_validation_of_the_round2_entry_points():
     assert lib.sqfa_sphere_backward(fake, fake, 4, 8, 0, z, 3, z, z, fake, z) == -1          # groups without partial sums
     assert lib.sqfa_embed_backward_means(fake, z, 3, 4, 0, fake, z) == -1
     assert lib.sqfa_feature_scatters_ex(fake, 4, 10, fake, 3, 0, 0.0, z, fake, z) == -2       # D % 4 != 0
-    assert lib.sqfa_feature_scatters_backward_ex(fake, 3, fake, 3, 8, 4, 0, 2, fake, z) == -1  # ldg < K
-    assert lib.sqfa_feature_scatters_backward_ex(fake, 70, fake, 3, 8, 65, 0, 2, fake, z) == -2  # K > 64
+    assert lib.sqfa_feature_scatters_backward_ex(fake, 3, fake, 3, 8, 4, 0, 2, 0, fake, z) == -1  # ldg < K
+    assert lib.sqfa_feature_scatters_backward_ex(fake, 70, fake, 3, 8, 65, 0, 2, 1, fake, z) == -2  # K > 64
     # L-BFGS
     assert lib.sqfa_lbfgs_max_history() >= 100
     assert lib.sqfa_lbfgs_push(fake, fake, fake, 200, 10, 0, fake, fake, 0, z) == -1          # history too long

@@ -355,6 +355,35 @@ def test_streaming_projection_vs_torch(C, D, K, native_products, monkeypatch):
     assert rel_err(Fd.grad.cpu(), F64.grad) < 1e-13
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("C,D,K,ldg", [(9, 64, 16, 16), (9, 64, 16, 17), (5, 40, 6, 6), (5, 40, 6, 7), (4, 132, 32, 32),
+                                       (3, 100, 33, 34), (70, 48, 12, 13), (2, 256, 64, 64)])
+def test_backward_product_general_and_symmetric(C, D, K, ldg, dtype):
+    """sqfa_feature_scatters_backward_ex: sum over groups of the partial sums = sum_c (G_c + G_c^T) T_c^T, for a general
+    G (g_symmetric = 0) and for a symmetric one read along rows only (g_symmetric = 1: what the closure passes for
+    the pair kernels' dL/dS), with row pitch K and K + 1 (gradient wrt the embedding), vector and scalar loads."""
+    import ctypes
+    from sqfa_amd import _lib
+    lib = _lib.load()
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+    g = torch.Generator().manual_seed(C * 100 + D + K + ldg)
+    T = torch.randn(C, D, K, generator=g, dtype=torch.float64)
+    G = torch.randn(C, ldg, ldg, generator=g, dtype=torch.float64)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    code = _lib.SQFA_F32 if dtype == torch.float32 else _lib.SQFA_F64
+    tol = 2e-6 if dtype == torch.float32 else 1e-13
+    for sym in (0, 1):
+        Gs = G + G.transpose(1, 2) if sym else G
+        Gk = Gs[:, :K, :K]
+        expect = torch.einsum("cab,cdb->ad", Gk + Gk.transpose(1, 2), T)
+        for groups in (1, 3, min(C, 64)):
+            partial = torch.full((groups, K, D), float("nan"), dtype=dtype, device=DEV)
+            Td, Gd = T.to(DEV, dtype).contiguous(), Gs.to(DEV, dtype).contiguous()
+            _lib.check(lib.sqfa_feature_scatters_backward_ex(ptr(Gd), ldg, ptr(Td), C, D, K, code, groups, sym, ptr(partial),
+                                                             stream), "sqfa_feature_scatters_backward_ex")
+            assert rel_err(partial.sum(0).cpu().double(), expect) < tol
+
+
 def test_transform_scatters_nonsymmetric_input_takes_general_path():
     """conjugate_matrix is general (reference src/sqfa/linalg.py:19-45) while the streaming kernel
     assumes symmetric scatters: a non-symmetric batch must be detected (once per tensor) and routed
