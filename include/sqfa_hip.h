@@ -189,11 +189,14 @@ int sqfa_sphere_backward(const void *X, const void *norms, int K, int D, int dty
  *   S, Y (h, n): ring buffers of steps and gradient differences; SY (h, h): SY[i][j] = s_i . y_j; h <= 128
  *   sqfa_lbfgs_push        writes (s, y) into ring row `slot` and refreshes row and column `slot` of SY
  *   sqfa_lbfgs_direction   d_out (n) = -H g for the k pairs listed (HOST array `slots`, chronological order);
- *                          H_diag: device scalar (initial Hessian scale) or NULL = 1; work: 3 h + n elements
+ *                          H_diag: device scalar (initial Hessian scale) or NULL = 1
+ *   work                   scratch of sqfa_lbfgs_work_elems(h, n) elements of the dtype, shared by both calls
+ *                          (partial dot products, solve vectors, one n-vector)
  */
 int sqfa_lbfgs_max_history(void);
-int sqfa_lbfgs_push(void *S, void *Y, void *SY, int h, int n, int slot, const void *s, const void *y, int dtype,
-                    void *stream);
+size_t sqfa_lbfgs_work_elems(int h, int n);
+int sqfa_lbfgs_push(void *S, void *Y, void *SY, int h, int n, int slot, const void *s, const void *y, void *work,
+                    int dtype, void *stream);
 int sqfa_lbfgs_direction(const void *S, const void *Y, const void *SY, int h, int n, const int *slots, int k,
                          const void *g, const void *H_diag, void *d_out, void *work, int dtype, void *stream);
 

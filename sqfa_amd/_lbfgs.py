@@ -43,7 +43,7 @@ class _History:
                 self._lib = lib
                 self._check = _lib.check
                 self._code = _lib.SQFA_F32 if like.dtype == torch.float32 else _lib.SQFA_F64
-                self._work = like.new_empty(3 * size + n)
+                self._work = like.new_empty(lib.sqfa_lbfgs_work_elems(size, n))
 
     def _stream(self):
         import ctypes
@@ -59,8 +59,8 @@ class _History:
             s, y = s.contiguous(), y.contiguous()
             with torch.cuda.device(self.S.device):
                 self._check(self._lib.sqfa_lbfgs_push(self.S.data_ptr(), self.Y.data_ptr(), self.SY.data_ptr(), self.size,
-                                                      self.S.shape[1], slot, s.data_ptr(), y.data_ptr(), self._code,
-                                                      self._stream()), "sqfa_lbfgs_push")
+                                                      self.S.shape[1], slot, s.data_ptr(), y.data_ptr(), self._work.data_ptr(),
+                                                      self._code, self._stream()), "sqfa_lbfgs_push")
             return
         self.S[slot] = s
         self.Y[slot] = y
@@ -106,12 +106,19 @@ class CompactLBFGS(torch.optim.LBFGS):
     # None: gather the per-iteration decision scalars in one device-to-host copy when the
     # parameters live on a GPU; True/False force the choice (tests run the fused path on the CPU)
     fuse_readback = None
+    # With the fused read-back, torch's test "g.d > -tolerance_change: stop before the step" is evaluated
+    # AFTER the step and its closure, in the same copy (it only fires at convergence): when it does, the
+    # parameters are restored and the extra evaluation is discarded -- same iterates, same counters, one host
+    # synchronisation per iteration instead of two.  A closure with a `deferred` attribute (sqfa_amd/_optim.py)
+    # hands its [loss, nan, inf] over on the device, so that copy is also the closure's: ONE per iteration.
+    speculate_descent_test = True
 
     @torch.no_grad()
     def step(self, closure):
         group = self.param_groups[0]
         if group["line_search_fn"] is not None:
             return super().step(closure)
+        raw_closure = closure
         closure = torch.enable_grad()(closure)
         lr = float(group["lr"])
         max_iter = group["max_iter"]
@@ -176,28 +183,51 @@ class CompactLBFGS(torch.optim.LBFGS):
                 t = lr
 
             gtd = flat_grad.dot(d)
-            if gtd > -tolerance_change:
-                break
+            fused = flat_grad.is_cuda if self.fuse_readback is None else self.fuse_readback
+            # first iteration of a fit: t was just read back anyway; last iteration of a step: no closure follows
+            speculate = fused and self.speculate_descent_test and n_iter != max_iter and state["n_iter"] != 1
+            if not speculate:
+                if gtd > -tolerance_change:
+                    break
+            else:
+                backup = self._clone_param()
 
             ls_func_evals = 0
             self._add_grad(t, d)
             step_max = None
             if n_iter != max_iter:
+                deferred = getattr(raw_closure, "deferred", None) if fused else None
+                head = None
                 with torch.enable_grad():
-                    loss_t = closure().detach()
+                    if deferred is not None:
+                        head = deferred()  # [loss, nan, inf] on the device, no synchronisation
+                    else:
+                        loss_t = closure().detach()
                 flat_grad = self._gather_flat_grad()
-                if flat_grad.is_cuda if self.fuse_readback is None else self.fuse_readback:
+                if fused:
                     # one read-back for everything the stopping rules need (instead of three
                     # synchronisations): loss, max |g|, max |t d|
                     # ... and s.y of the NEXT iteration, whose sign decides the history update
                     y_next, s_next = flat_grad.sub(prev_flat_grad), d.mul(t)
-                    parts = [flat_grad.abs().max(), s_next.abs().max(), y_next.dot(s_next)]
-                    if loss_t.device == flat_grad.device:
-                        parts.append(loss_t.to(flat_grad.dtype).reshape(()))
-                    vals = torch.stack(parts).tolist()
+                    parts = [flat_grad.abs().max(), s_next.abs().max(), y_next.dot(s_next),
+                             gtd if speculate else flat_grad.new_zeros(())]
+                    packed = torch.stack(parts)
+                    if head is not None:
+                        packed = torch.cat([packed, head.detach().to(flat_grad.dtype).reshape(3)])
+                    elif loss_t.device == flat_grad.device:
+                        packed = torch.cat([packed, loss_t.to(flat_grad.dtype).reshape(1)])
+                    vals = packed.tolist()
+                    if head is not None:
+                        raw_closure.check_flags(vals[5], vals[6])  # raises like the synchronous closure would have
+                    if speculate and vals[3] > -tolerance_change:
+                        # torch stops BEFORE this step: undo it, forget the extra evaluation
+                        self._set_param(backup)
+                        flat_grad = prev_flat_grad.clone(memory_format=torch.contiguous_format)
+                        loss = prev_loss
+                        break
                     g_max, step_max = vals[0], vals[1]
                     ahead = (y_next, s_next, vals[2])
-                    loss = vals[3] if loss_t.device == flat_grad.device else float(loss_t)
+                    loss = vals[4] if len(vals) > 4 else float(loss_t)
                     opt_cond = g_max <= tolerance_grad
                 else:
                     loss = float(loss_t)

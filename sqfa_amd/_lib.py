@@ -88,10 +88,11 @@ PROTOTYPES = {
          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
     ),
     "sqfa_lbfgs_max_history": (ctypes.c_int, []),
+    "sqfa_lbfgs_work_elems": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "sqfa_lbfgs_push": (
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p],
+         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p],
     ),
     "sqfa_lbfgs_direction": (
         ctypes.c_int,

@@ -35,6 +35,10 @@ HOST_SIDE_LBFGS = True
 HOST_SIDE_LBFGS_MAX_NUMEL = 32768
 HOST_SIDE_LBFGS_MAX_NUMEL_COMPACT = 8192
 HOST_SIDE_LBFGS_THREADS = 4  # intra-op threads while the optimizer state lives on the host
+# Device-side optimizer state: the closure hands [loss, nan, inf] to CompactLBFGS on the device (one host
+# synchronisation per LBFGS iteration instead of three, see _lbfgs.CompactLBFGS.speculate_descent_test).
+DEFERRED_CLOSURE = True
+
 # Use sqfa_amd._lbfgs.CompactLBFGS (torch.optim.LBFGS with the two-loop recursion evaluated as
 # two triangular solves: ~15 instead of ~400 vector operations per iteration).  False selects
 # torch.optim.LBFGS itself.
@@ -252,7 +256,7 @@ def fitting_loop(model, data_statistics, max_epochs=200, lr=0.1, atol=1e-6, show
             graphs.append(g)
         split.update(graphs=graphs, state="on")
 
-    def split_closure():
+    def split_closure(defer=False):
         push_parameters()
         if split.get("stages") is None:
             split["stages"] = split_stages()
@@ -277,6 +281,8 @@ def fitting_loop(model, data_statistics, max_epochs=200, lr=0.1, atol=1e-6, show
         device_params[0].grad = box["grad"]
         if use_host:
             return unpack_to_host(packed)
+        if defer:
+            return packed[:3]
         head = packed[:3].cpu()
         raise_on_flags(head[1:3].round().to(torch.int32))
         return head[0]
@@ -296,9 +302,12 @@ def fitting_loop(model, data_statistics, max_epochs=200, lr=0.1, atol=1e-6, show
             packed = pack(loss, flags)
         graph.update(graph=g, packed=packed, grads=[p.grad for p in device_params], state="on")
 
-    def closure():
+    def closure(defer=False):
+        """defer=True (device-side optimizer state only): enqueue everything and return [loss, nan, inf] as a
+        DEVICE tensor without synchronising -- CompactLBFGS reads it back together with its own decision
+        scalars and then calls closure.check_flags (one host synchronisation per LBFGS iteration)."""
         if split["state"] != "off":
-            return split_closure()
+            return split_closure(defer)
         push_parameters()
         if graph["state"] == "warmup" and graph["calls"] >= GRAPH_WARMUP_CLOSURES:
             try:
@@ -313,6 +322,8 @@ def fitting_loop(model, data_statistics, max_epochs=200, lr=0.1, atol=1e-6, show
                 p.grad = grad  # the static gradient tensors the graph writes
             if use_host:
                 return unpack_to_host(packed)
+            if defer:
+                return packed[:3]
             head = packed[:3].cpu()  # loss and flags in one read-back; the gradient stays on the device
             raise_on_flags(head[1:3].round().to(torch.int32))
             return head[0]
@@ -322,9 +333,15 @@ def fitting_loop(model, data_statistics, max_epochs=200, lr=0.1, atol=1e-6, show
         loss, flags = evaluate()
         if use_host:
             return unpack_to_host(pack(loss, flags))
+        if defer:
+            return torch.cat([loss.reshape(1), flags.to(loss.dtype) if flags is not None else loss.new_zeros(2)])
         if flags is not None:
             raise_on_flags(flags)
         return loss
+
+    if DEFERRED_CLOSURE and not use_host and len(device_params) > 0 and all(p.is_cuda for p in device_params):
+        closure.deferred = lambda: closure(True)
+        closure.check_flags = lambda n_nan, n_inf: raise_on_flags(torch.tensor([round(n_nan), round(n_inf)], dtype=torch.int32))
 
     losses, times = [], []
     start = time.time()

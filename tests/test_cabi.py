@@ -106,8 +106,9 @@ def test_argument_validation_of_the_round2_entry_points():
     assert lib.sqfa_feature_scatters_backward_ex(fake, 70, fake, 3, 8, 65, 0, 2, 1, fake, z) == -2  # K > 64
     # L-BFGS
     assert lib.sqfa_lbfgs_max_history() >= 100
-    assert lib.sqfa_lbfgs_push(fake, fake, fake, 200, 10, 0, fake, fake, 0, z) == -1          # history too long
-    assert lib.sqfa_lbfgs_push(fake, fake, fake, 10, 10, 10, fake, fake, 0, z) == -1          # slot out of range
+    assert lib.sqfa_lbfgs_work_elems(100, 50000) >= 3 * 100 + 50000 and lib.sqfa_lbfgs_work_elems(500, 10) == 0
+    assert lib.sqfa_lbfgs_push(fake, fake, fake, 200, 10, 0, fake, fake, fake, 0, z) == -1          # history too long
+    assert lib.sqfa_lbfgs_push(fake, fake, fake, 10, 10, 10, fake, fake, fake, 0, z) == -1          # slot out of range
     slots = (ctypes.c_int * 2)(0, 11)
     assert lib.sqfa_lbfgs_direction(fake, fake, fake, 10, 10, slots, 2, fake, z, fake, fake, 0, z) == -1   # bad slot
     # per-shard workspace: never more than the any-shard bound, and decreasing with the shard's share

@@ -42,6 +42,69 @@ def test_matches_torch_lbfgs(dtype, tol, history_size, fuse_readback, monkeypatc
     assert torch.linalg.norm(xa - xb) <= tol * torch.linalg.norm(xa)
 
 
+@pytest.mark.parametrize("deferred", [False, True])
+def test_speculative_descent_test_rolls_back_at_convergence(deferred, monkeypatch):
+    """Fused read-back path: torch's test g.d > -tolerance_change (stop BEFORE the step) is evaluated after the
+    step and its closure; when it fires the parameters must be restored and the extra evaluation must not be
+    counted -- iterates, n_iter and func_evals equal torch.optim.LBFGS' through convergence and beyond.  With
+    `deferred` the closure hands [loss, nan, inf] over as a tensor and its flags are checked by the optimizer."""
+    monkeypatch.setattr(CompactLBFGS, "fuse_readback", True)
+    A = torch.diag(torch.linspace(0.5, 3.0, 12, dtype=torch.float64))
+    x0 = torch.linspace(-1, 1, 12, dtype=torch.float64)
+    runs = []
+    for cls in (torch.optim.LBFGS, CompactLBFGS):
+        x = torch.nn.Parameter(x0.clone())
+        opt = cls([x], lr=1.0, history_size=8)
+        calls, checked = [0], [0]
+
+        def closure():
+            opt.zero_grad()
+            calls[0] += 1
+            loss = 0.5 * x @ A @ x
+            loss.backward()
+            return loss
+
+        if deferred and cls is CompactLBFGS:
+            closure.deferred = lambda: torch.cat([closure().detach().reshape(1), torch.zeros(2, dtype=torch.float64)])
+
+            def check_flags(n_nan, n_inf):
+                checked[0] += 1
+                assert n_nan == 0 and n_inf == 0
+            closure.check_flags = check_flags
+        losses = [opt.step(closure).item() for _ in range(6)]  # converges inside the second step; later steps stop at once
+        runs.append((x.detach().clone(), losses, calls[0], opt.state[x]["n_iter"], opt.state[x]["func_evals"], checked[0]))
+    (xa, la, ca, na, fa, _), (xb, lb, cb, nb, fb, checked) = runs
+    assert (na, fa) == (nb, fb)
+    assert cb >= ca                       # the discarded evaluations are extra closure calls, never counted ones
+    assert torch.allclose(torch.tensor(la), torch.tensor(lb), rtol=1e-12, atol=1e-14)
+    assert torch.linalg.norm(xa - xb) <= 1e-12
+    assert (checked > 0) == deferred
+
+
+def test_deferred_closure_flags_raise(monkeypatch):
+    monkeypatch.setattr(CompactLBFGS, "fuse_readback", True)
+    x = torch.nn.Parameter(torch.ones(5, dtype=torch.float64))
+    opt = CompactLBFGS([x], lr=0.1)
+    n = [0]
+
+    def closure():
+        opt.zero_grad()
+        loss = (x ** 2).sum()
+        loss.backward()
+        return loss
+
+    def deferred():
+        n[0] += 1
+        return torch.cat([closure().detach().reshape(1), torch.tensor([1.0 if n[0] >= 2 else 0.0, 0.0], dtype=torch.float64)])
+
+    def check_flags(n_nan, n_inf):
+        if n_nan:
+            raise ValueError("nan in distances")
+    closure.deferred, closure.check_flags = deferred, check_flags
+    with pytest.raises(ValueError, match="nan in distances"):
+        opt.step(closure)
+
+
 def test_line_search_defers_to_torch():
     x = torch.nn.Parameter(torch.tensor([1.5, -0.5], dtype=torch.float64))
     opt = CompactLBFGS([x], lr=1.0, line_search_fn="strong_wolfe")
