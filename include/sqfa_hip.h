@@ -197,6 +197,10 @@ int sqfa_lbfgs_max_history(void);
 size_t sqfa_lbfgs_work_elems(int h, int n);
 int sqfa_lbfgs_push(void *S, void *Y, void *SY, int h, int n, int slot, const void *s, const void *y, void *work,
                     int dtype, void *stream);
+/* y_out = g - g_prev, s_out = t d, scalars_out (5) = [max|g|, max|s|, y.s, y.y, y.s / y.y]: the element-wise part of an
+ * iteration and its stopping-rule scalars in two launches; work: sqfa_lbfgs_work_elems(h, n) >= 1024 elements */
+int sqfa_lbfgs_step_stats(const void *g, const void *g_prev, const void *d, double t, int n, void *y_out, void *s_out,
+                          void *scalars_out, void *work, int dtype, void *stream);
 int sqfa_lbfgs_direction(const void *S, const void *Y, const void *SY, int h, int n, const int *slots, int k,
                          const void *g, const void *H_diag, void *d_out, void *work, int dtype, void *stream);
 

@@ -67,6 +67,20 @@ class _History:
         self.SY[slot, :] = self.Y @ s   # s_new . y_j
         self.SY[:, slot] = self.S @ y   # s_i . y_new
 
+    def step_stats(self, flat_grad, prev_flat_grad, d, t):
+        """(y, s, scalars) with y = g - g_prev, s = t d and the DEVICE vector scalars = [max|g|, max|s|, y.s, y.y,
+        y.s / y.y] in two launches (sqfa_lbfgs_step_stats); None without the native library."""
+        if self._lib is None:
+            return None
+        g, gp, dd = flat_grad.contiguous(), prev_flat_grad.contiguous(), d.contiguous()
+        y, s = torch.empty_like(g), torch.empty_like(g)
+        scal = g.new_empty(5)
+        with torch.cuda.device(g.device):
+            self._check(self._lib.sqfa_lbfgs_step_stats(g.data_ptr(), gp.data_ptr(), dd.data_ptr(), float(t), g.numel(),
+                                                        y.data_ptr(), s.data_ptr(), scal.data_ptr(), self._work.data_ptr(),
+                                                        self._code, self._stream()), "sqfa_lbfgs_step_stats")
+        return y, s, scal
+
     def direction(self, flat_grad, H_diag):
         q0 = flat_grad.neg()
         k = len(self.slots)
@@ -159,8 +173,9 @@ class CompactLBFGS(torch.optim.LBFGS):
                 hist = _History(history_size, flat_grad)
                 H_diag = 1
             else:
+                H_next = None
                 if ahead is not None:
-                    y, s, ys = ahead  # formed (and ys read back) together with the stopping-rule scalars
+                    y, s, ys, H_next = ahead  # formed (and ys read back) together with the stopping-rule scalars
                     ahead = None
                 else:
                     y = flat_grad.sub(prev_flat_grad)
@@ -168,7 +183,7 @@ class CompactLBFGS(torch.optim.LBFGS):
                     ys = y.dot(s)
                 if ys > 1e-10:
                     hist.push(y, s)
-                    H_diag = ys / y.dot(y)
+                    H_diag = H_next if H_next is not None else ys / y.dot(y)
                 d = hist.direction(flat_grad, H_diag)
 
             if prev_flat_grad is None:
@@ -208,10 +223,16 @@ class CompactLBFGS(torch.optim.LBFGS):
                     # one read-back for everything the stopping rules need (instead of three
                     # synchronisations): loss, max |g|, max |t d|
                     # ... and s.y of the NEXT iteration, whose sign decides the history update
-                    y_next, s_next = flat_grad.sub(prev_flat_grad), d.mul(t)
-                    parts = [flat_grad.abs().max(), s_next.abs().max(), y_next.dot(s_next),
-                             gtd if speculate else flat_grad.new_zeros(())]
-                    packed = torch.stack(parts)
+                    native = hist.step_stats(flat_grad, prev_flat_grad, d, t) if flat_grad.is_cuda else None
+                    if native is not None:
+                        y_next, s_next, scal = native
+                        H_next = scal[4]   # y.s / y.y, on the device: torch's H_diag if the pair is accepted
+                        packed = torch.cat([scal[:3], gtd.reshape(1) if speculate else scal.new_zeros(1)])
+                    else:
+                        y_next, s_next, H_next = flat_grad.sub(prev_flat_grad), d.mul(t), None
+                        parts = [flat_grad.abs().max(), s_next.abs().max(), y_next.dot(s_next),
+                                 gtd if speculate else flat_grad.new_zeros(())]
+                        packed = torch.stack(parts)
                     if head is not None:
                         packed = torch.cat([packed, head.detach().to(flat_grad.dtype).reshape(3)])
                     elif loss_t.device == flat_grad.device:
@@ -226,7 +247,7 @@ class CompactLBFGS(torch.optim.LBFGS):
                         loss = prev_loss
                         break
                     g_max, step_max = vals[0], vals[1]
-                    ahead = (y_next, s_next, vals[2])
+                    ahead = (y_next, s_next, vals[2], H_next)
                     loss = vals[4] if len(vals) > 4 else float(loss_t)
                     opt_cond = g_max <= tolerance_grad
                 else:

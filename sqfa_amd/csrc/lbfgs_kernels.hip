@@ -214,6 +214,77 @@ __global__ __launch_bounds__(256) void lb_store_rows(T* __restrict__ S, T* __res
   Y[(size_t)slot * n + e] = y[e];
 }
 
+// The element-wise part of an iteration and its decision scalars in two launches (torch: sub, mul, abs, max, abs,
+// max, dot, dot, div, stack -- a dozen launches): y = g - g_prev, s = t d, and
+//   out = [max|g|, max|s|, y.s, y.y, y.s / y.y]
+// (the last one is torch's H_diag for the next direction, valid when the pair is accepted).  Block partials are
+// combined in index order by the second launch: reproducible.
+constexpr int LB_STAT_BLOCKS = 256;
+template <typename T>
+__global__ __launch_bounds__(256) void lb_step_stats(const T* __restrict__ g, const T* __restrict__ g_prev, const T* __restrict__ d,
+                                                     T t, int n, T* __restrict__ y, T* __restrict__ sv, T* __restrict__ part) {
+  __shared__ T s_red[256];
+  T gmax = T(0), smax = T(0), ys = T(0), yy = T(0);
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    const T ge = g[e], ye = ge - g_prev[e], se = t * d[e];
+    y[e] = ye;
+    sv[e] = se;
+    gmax = fmax(gmax, fabs(ge));
+    smax = fmax(smax, fabs(se));
+    ys += ye * se;
+    yy += ye * ye;
+  }
+  const T ys_b = lb_block_sum(ys, s_red);
+  __syncthreads();
+  const T yy_b = lb_block_sum(yy, s_red);
+  __syncthreads();
+  // maxima: same tree with max
+  auto block_max = [&](T v) {
+    s_red[threadIdx.x] = v;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if (threadIdx.x < st) s_red[threadIdx.x] = fmax(s_red[threadIdx.x], s_red[threadIdx.x + st]);
+      __syncthreads();
+    }
+    const T r = s_red[0];
+    __syncthreads();
+    return r;
+  };
+  const T gm_b = block_max(gmax), sm_b = block_max(smax);
+  if (threadIdx.x == 0) {
+    part[4 * blockIdx.x + 0] = gm_b;
+    part[4 * blockIdx.x + 1] = sm_b;
+    part[4 * blockIdx.x + 2] = ys_b;
+    part[4 * blockIdx.x + 3] = yy_b;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(64) void lb_step_stats_finish(const T* __restrict__ part, int blocks, T* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  T gmax = T(0), smax = T(0), ys = T(0), yy = T(0);
+  for (int b = 0; b < blocks; ++b) {
+    gmax = fmax(gmax, part[4 * b + 0]);
+    smax = fmax(smax, part[4 * b + 1]);
+    ys += part[4 * b + 2];
+    yy += part[4 * b + 3];
+  }
+  out[0] = gmax;
+  out[1] = smax;
+  out[2] = ys;
+  out[3] = yy;
+  out[4] = ys / yy;
+}
+
+template <typename T>
+static int step_stats_impl(const T* g, const T* g_prev, const T* d, double t, int n, T* y, T* s, T* out, T* work, hipStream_t stream) {
+  int blocks = (n + 1023) / 1024;  // >= 4 elements per thread
+  if (blocks > LB_STAT_BLOCKS) blocks = LB_STAT_BLOCKS;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(lb_step_stats<T>, dim3(blocks), dim3(256), 0, stream, g, g_prev, d, (T)t, n, y, s, work);
+  hipLaunchKernelGGL(lb_step_stats_finish<T>, dim3(1), dim3(64), 0, stream, (const T*)work, blocks, out);
+  return hipGetLastError() == hipSuccess ? SQFA_OK : SQFA_ERR_LAUNCH;
+}
+
 template <typename T> static bool lb_vec_ok(int n, int chunk, const void* a, const void* b, const void* c) {
   const size_t al = 4 * sizeof(T);
   return (n % 4) == 0 && (chunk % 4) == 0 && (reinterpret_cast<size_t>(a) % al) == 0 && (reinterpret_cast<size_t>(b) % al) == 0 &&
@@ -291,7 +362,8 @@ extern "C" int sqfa_lbfgs_max_history(void) { return LB_MAX_HISTORY; }
 
 extern "C" size_t sqfa_lbfgs_work_elems(int h, int n) {
   if (h < 1 || h > LB_MAX_HISTORY || n < 1) return 0;
-  return 2 * (size_t)h + 2 * (size_t)h * LB_MAX_PARTS + (size_t)n;
+  const size_t direction = 2 * (size_t)h + 2 * (size_t)h * LB_MAX_PARTS + (size_t)n, stats = 4 * (size_t)LB_STAT_BLOCKS;
+  return direction > stats ? direction : stats;
 }
 
 extern "C" int sqfa_lbfgs_push(void* S, void* Y, void* SY, int h, int n, int slot, const void* s, const void* y, void* work,
@@ -306,6 +378,23 @@ extern "C" int sqfa_lbfgs_push(void* S, void* Y, void* SY, int h, int n, int slo
   if (dtype == SQFA_F64)
     return push_impl(static_cast<double*>(S), static_cast<double*>(Y), static_cast<double*>(SY), h, n, slot,
                      static_cast<const double*>(s), static_cast<const double*>(y), static_cast<double*>(work), stream);
+  return SQFA_ERR_BAD_ARGUMENT;
+}
+
+extern "C" int sqfa_lbfgs_step_stats(const void* g, const void* g_prev, const void* d, double t, int n, void* y_out,
+                                     void* s_out, void* scalars_out, void* work, int dtype, void* stream_) {
+  if (g == nullptr || g_prev == nullptr || d == nullptr || y_out == nullptr || s_out == nullptr || scalars_out == nullptr ||
+      work == nullptr || n < 1)
+    return SQFA_ERR_BAD_ARGUMENT;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (dtype == SQFA_F32)
+    return step_stats_impl(static_cast<const float*>(g), static_cast<const float*>(g_prev), static_cast<const float*>(d), t, n,
+                           static_cast<float*>(y_out), static_cast<float*>(s_out), static_cast<float*>(scalars_out),
+                           static_cast<float*>(work), stream);
+  if (dtype == SQFA_F64)
+    return step_stats_impl(static_cast<const double*>(g), static_cast<const double*>(g_prev), static_cast<const double*>(d), t, n,
+                           static_cast<double*>(y_out), static_cast<double*>(s_out), static_cast<double*>(scalars_out),
+                           static_cast<double*>(work), stream);
   return SQFA_ERR_BAD_ARGUMENT;
 }
 

@@ -106,6 +106,7 @@ def test_argument_validation_of_the_round2_entry_points():
     assert lib.sqfa_feature_scatters_backward_ex(fake, 70, fake, 3, 8, 65, 0, 2, 1, fake, z) == -2  # K > 64
     # L-BFGS
     assert lib.sqfa_lbfgs_max_history() >= 100
+    assert lib.sqfa_lbfgs_step_stats(fake, fake, fake, 1.0, 0, fake, fake, fake, fake, 0, z) == -1   # n < 1
     assert lib.sqfa_lbfgs_work_elems(100, 50000) >= 3 * 100 + 50000 and lib.sqfa_lbfgs_work_elems(500, 10) == 0
     assert lib.sqfa_lbfgs_push(fake, fake, fake, 200, 10, 0, fake, fake, fake, 0, z) == -1          # history too long
     assert lib.sqfa_lbfgs_push(fake, fake, fake, 10, 10, 10, fake, fake, fake, 0, z) == -1          # slot out of range

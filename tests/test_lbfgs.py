@@ -155,3 +155,21 @@ def test_native_lbfgs_direction_matches_torch_compact_form(n, h, pushes, dtype, 
     assert torch.allclose(nat.SY.index_select(0, idx).index_select(1, idx), ref.SY.index_select(0, idx).index_select(1, idx),
                           rtol=1e-10 if dtype == torch.float64 else 1e-4, atol=1e-12 if dtype == torch.float64 else 1e-3)
     assert torch.equal(nat.S, ref.S) and torch.equal(nat.Y, ref.Y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-13), (torch.float32, 2e-6)])
+@pytest.mark.parametrize("n", [5, 1000, 12544, 49152, 300001])
+def test_native_step_stats_matches_torch(n, dtype, tol):
+    """sqfa_lbfgs_step_stats: y = g - g_prev, s = t d (exact) and [max|g|, max|s|, y.s, y.y, y.s / y.y]."""
+    from sqfa_amd._lbfgs import _History
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(n)
+    g, gp, d = (torch.randn(n, generator=gen, dtype=torch.float64).to(dev, dtype) for _ in range(3))
+    hist = _History(10, g)
+    y, s, scal = hist.step_stats(g, gp, d, 0.37)
+    assert torch.equal(y, g - gp) and torch.equal(s, d * 0.37)
+    y64, s64 = (g - gp).double(), (d * 0.37).double()
+    expect = torch.stack([g.abs().max().double(), s.abs().max().double(), y64.dot(s64), y64.dot(y64), y64.dot(s64) / y64.dot(y64)])
+    assert torch.allclose(scal.double(), expect, rtol=tol, atol=tol * float(y64.abs().max() * s64.abs().max()) * n ** 0.5)
+    assert torch.equal(scal[:2], torch.stack([g.abs().max(), s.abs().max()]))
