@@ -8,6 +8,8 @@ is one of the native affine-invariant operators the closure issues ONE fused
 loss+gradient launch (no (C,C) matrix, no tril gather, validity flag read with the loss)
 instead of the reference's distance-matrix -> guard -> gather -> mean chain.
 """
+import contextlib
+import gc
 import time
 import warnings
 
@@ -33,7 +35,12 @@ def __dir__():
 # slower than the GPU launches on an oversubscribed host.
 HOST_SIDE_LBFGS = True
 HOST_SIDE_LBFGS_MAX_NUMEL = 32768
-HOST_SIDE_LBFGS_MAX_NUMEL_COMPACT = 8192
+# CompactLBFGS without a line search keeps its state on the DEVICE at every size since late round 2 (native
+# push / direction / statistics kernels, one synchronisation per iteration: c2-SQFA 0.47 -> 0.31 ms per closure,
+# c1 0.35 -> 0.32; tools/ab_host_vs_device_lbfgs.py); with a line search (torch's own step) small parameters
+# stay on the host as before.
+HOST_SIDE_LBFGS_MAX_NUMEL_COMPACT = 0
+HOST_SIDE_LBFGS_MAX_NUMEL_LINE_SEARCH = 8192
 HOST_SIDE_LBFGS_THREADS = 4  # intra-op threads while the optimizer state lives on the host
 # Device-side optimizer state: the closure hands [loss, nan, inf] to CompactLBFGS on the device (one host
 # synchronisation per LBFGS iteration instead of three, see _lbfgs.CompactLBFGS.speculate_descent_test).
@@ -66,6 +73,20 @@ def check_distances_valid(distances):
         raise ValueError(_NAN_MSG)
     if torch.isinf(distances).any():
         raise ValueError(_INF_MSG)
+
+
+@contextlib.contextmanager
+def _no_gc():
+    """No cyclic garbage collection while a stream is capturing: a collection that finalises device tensors or an
+    older CUDAGraph in the middle of a capture aborts the process (seen in the GPU test suite: 'Fatal Python
+    error: Aborted ... Garbage-collecting' inside the captured closure)."""
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 def raise_on_flags(flags):
@@ -109,7 +130,12 @@ def fitting_loop(model, data_statistics, max_epochs=200, lr=0.1, atol=1e-6, show
     device_params = list(model.parameters())
     # the compact form is four (history x n) matrix-vector products per iteration: on the host
     # only while they are a fraction of a millisecond, otherwise on the device
-    host_limit = HOST_SIDE_LBFGS_MAX_NUMEL_COMPACT if COMPACT_LBFGS else HOST_SIDE_LBFGS_MAX_NUMEL
+    if not COMPACT_LBFGS:
+        host_limit = HOST_SIDE_LBFGS_MAX_NUMEL
+    elif kwargs.get("line_search_fn") is not None:
+        host_limit = HOST_SIDE_LBFGS_MAX_NUMEL_LINE_SEARCH
+    else:
+        host_limit = HOST_SIDE_LBFGS_MAX_NUMEL_COMPACT
     use_host = (HOST_SIDE_LBFGS and len(device_params) > 0 and all(p.is_cuda for p in device_params)
                 and sum(p.numel() for p in device_params) <= host_limit)
     if use_host:
@@ -250,7 +276,7 @@ def fitting_loop(model, data_statistics, max_epochs=200, lr=0.1, atol=1e-6, show
                 graphs.append(None)
                 continue
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            with _no_gc(), torch.cuda.graph(g, pool=pool):
                 stage()
             pool = g.pool()
             graphs.append(g)
@@ -297,7 +323,7 @@ def fitting_loop(model, data_statistics, max_epochs=200, lr=0.1, atol=1e-6, show
         for p in device_params:
             p.grad = None
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with _no_gc(), torch.cuda.graph(g):
             loss, flags = evaluate()
             packed = pack(loss, flags)
         graph.update(graph=g, packed=packed, grads=[p.grad for p in device_params], state="on")

@@ -291,6 +291,7 @@ def test_graph_captured_closure_matches_eager(model_name, host_lbfgs, monkeypatc
     import sqfa_amd._optim as opt
     stats = {k: v.to(DEV) for k, v in mc.c2_statistics(C=24, D=96).items()}
     monkeypatch.setattr(opt, "HOST_SIDE_LBFGS", host_lbfgs)
+    monkeypatch.setattr(opt, "HOST_SIDE_LBFGS_MAX_NUMEL_COMPACT", 8192)  # host_lbfgs=True: the host-side state (the default only with a line search)
     replays = [0]
     original_replay = torch.cuda.CUDAGraph.replay
 
