@@ -21,7 +21,11 @@ namespace sqfa {
 // in one wave would leave 4 loads in flight); the SPLIT partial tiles are summed through LDS.
 // step s contracts d = 4s .. 4s+3:  A[i][k] = F[16 w + i][4 s + k],  B[k][j] = T_c[4 s + k][16 nb + j]
 // (for K = 16 the 64 lanes of a wave read 256 contiguous bytes of T per step).
-template <typename T, int NB, int SPLIT>
+// FV: a lane reads its four F elements of FOUR consecutive steps as one 16-byte (float64: 32-byte) load: the group
+// of steps 4S .. 4S+3 then contracts d = 16 S + 4 k + e in MFMA e (k = the lane's quarter) instead of d = 4 s + k,
+// same sums in a different order.  The kernel is bound by the number of load instructions (the 16-row x 16-byte
+// footprint of the scalar F load costs as much as a T load): 8 -> 5 per four steps at K = 16.
+template <typename T, int NB, int SPLIT, bool FV>
 __global__ __launch_bounds__(64 * NB * SPLIT) void feature_scatters_kernel(const T* __restrict__ F,
                                                                            const T* __restrict__ Tm,
                                                                            T* __restrict__ S, int D, int K, T noise,
@@ -41,8 +45,28 @@ __global__ __launch_bounds__(64 * NB * SPLIT) void feature_scatters_kernel(const
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) acc[nb][reg] = T(0);
   const int steps = D / 4;
+  int first_scalar_step = part;
+  if constexpr (FV) {
+    struct alignas(4 * sizeof(T)) Vec4 { T v[4]; };
+    const int groups = steps / 4;
+    const T* __restrict__ frow = F + (size_t)(row < K ? row : 0) * D + 4 * q;
+#pragma unroll 2
+    for (int S = part; S < groups; S += SPLIT) {
+      Vec4 a4 = {{T(0), T(0), T(0), T(0)}};
+      if (row < K) a4 = *reinterpret_cast<const Vec4*>(frow + 16 * S);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const T b = (16 * nb + r16 < K) ? t[(size_t)(16 * S + 3 * q + e) * K + 16 * nb] : T(0);  // row 16 S + 4 q + e (t holds + q)
+          acc[nb] = Tr::mfma(a4.v[e], b, acc[nb]);
+        }
+      }
+    }
+    first_scalar_step = 4 * groups + part;  // the D % 16 tail, one step at a time
+  }
 #pragma unroll 8
-  for (int s = part; s < steps; s += SPLIT) {
+  for (int s = first_scalar_step; s < steps; s += SPLIT) {
     const T a = row < K ? f[4 * s] : T(0);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -168,12 +192,21 @@ __global__ __launch_bounds__(64) void feature_backward_kernel(const T* __restric
 template <typename T>
 static void launch_forward(const T* f, const T* t, T* s, int C, int D, int K, T noise, const T* means, int ld,
                            hipStream_t stream) {
+  const bool fv = (reinterpret_cast<size_t>(f) % (4 * sizeof(T))) == 0 && D >= 16;  // D % 4 == 0: every row is aligned then
+#define SQFA_FWD(NB_, SPLIT_, THREADS_)                                                                                     \
+  if (fv)                                                                                                                   \
+    hipLaunchKernelGGL((feature_scatters_kernel<T, NB_, SPLIT_, true>), dim3(C), dim3(THREADS_), 0, stream, f, t, s, D, K, \
+                       noise, means, ld);                                                                                   \
+  else                                                                                                                      \
+    hipLaunchKernelGGL((feature_scatters_kernel<T, NB_, SPLIT_, false>), dim3(C), dim3(THREADS_), 0, stream, f, t, s, D, K, \
+                       noise, means, ld);
   switch ((K + 15) / 16) {
-    case 1: hipLaunchKernelGGL((feature_scatters_kernel<T, 1, 8>), dim3(C), dim3(512), 0, stream, f, t, s, D, K, noise, means, ld); break;
-    case 2: hipLaunchKernelGGL((feature_scatters_kernel<T, 2, 4>), dim3(C), dim3(512), 0, stream, f, t, s, D, K, noise, means, ld); break;
-    case 3: hipLaunchKernelGGL((feature_scatters_kernel<T, 3, 2>), dim3(C), dim3(384), 0, stream, f, t, s, D, K, noise, means, ld); break;
-    default: hipLaunchKernelGGL((feature_scatters_kernel<T, 4, 2>), dim3(C), dim3(512), 0, stream, f, t, s, D, K, noise, means, ld); break;
+    case 1: SQFA_FWD(1, 8, 512) break;
+    case 2: SQFA_FWD(2, 4, 512) break;
+    case 3: SQFA_FWD(3, 2, 384) break;
+    default: SQFA_FWD(4, 2, 512) break;
   }
+#undef SQFA_FWD
 }
 
 template <typename T, bool TV, bool SYM, bool GV>
