@@ -318,22 +318,43 @@ __global__ __launch_bounds__(SQFA_K2_THREADS) void finalize_kernel(const PairPar
     }
     T acc = T(0);
     if (idx < TRI && grp < NG) {
-      for (int q = grp; q < n_a + n_b; q += NG) {
-        if (q < n_a) {
-          // the q-th owned tile of block-row bi_a (bj = first_a + q N)
-          acc += slab[(size_t)(row_start_of(bi_a) + q) * tile_stride + (size_t)pi * TRI + idx];
-        } else {
-          const int bi = first_b + (q - n_a) * N;
-          if (tile_processed(p, bi, bj_b, TI, TJ)) {
-            int slot = row_start_of(bi) + bj_b;  // single shard: every tile of the row is owned
-            if (N > 1) {
-              const int first_in_row = ((p.shard_index - bi) % N + N) % N;
-              slot = row_start_of(bi) + (bj_b - first_in_row) / N;
-            }
-            acc += slab[(size_t)slot * tile_stride + (size_t)(TI + pj) * TRI + idx];
-          }
+      // group `grp` sums every NG-th A-side tile and every NG-th B-side tile, four independent partial sums each:
+      // the loads of a thread do not depend on each other, and one accumulator made the ~60 of them one chain
+      // (c3: 30 -> 17 us, m=32: 202 -> 120 us).  Fixed association order: reproducible.
+      T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
+      {
+        // the q-th owned tile of block-row bi_a (bj = first_a + q N) sits in slab slot row_start + q
+        const T* base = slab + (size_t)row_start_of(bi_a) * tile_stride + (size_t)pi * TRI + idx;
+        int q = grp;
+        for (; q + 3 * NG < n_a; q += 4 * NG) {
+          a0 += base[(size_t)q * tile_stride];
+          a1 += base[(size_t)(q + NG) * tile_stride];
+          a2 += base[(size_t)(q + 2 * NG) * tile_stride];
+          a3 += base[(size_t)(q + 3 * NG) * tile_stride];
         }
+        for (; q < n_a; q += NG) a0 += base[(size_t)q * tile_stride];
       }
+      {
+        auto b_tile = [&](int k) -> T {
+          const int bi = first_b + k * N;
+          if (!tile_processed(p, bi, bj_b, TI, TJ)) return T(0);
+          int slot = row_start_of(bi) + bj_b;  // single shard: every tile of the row is owned
+          if (N > 1) {
+            const int first_in_row = ((p.shard_index - bi) % N + N) % N;
+            slot = row_start_of(bi) + (bj_b - first_in_row) / N;
+          }
+          return slab[(size_t)slot * tile_stride + (size_t)(TI + pj) * TRI + idx];
+        };
+        int k = grp;
+        for (; k + 3 * NG < n_b; k += 4 * NG) {
+          a0 += b_tile(k);
+          a1 += b_tile(k + NG);
+          a2 += b_tile(k + 2 * NG);
+          a3 += b_tile(k + 3 * NG);
+        }
+        for (; k < n_b; k += NG) a0 += b_tile(k);
+      }
+      acc = (a0 + a1) + (a2 + a3);
     }
     s_part[tid] = acc;   // [grp][entry]: tid = grp * EPB + e_in
     __syncthreads();
