@@ -19,7 +19,7 @@ def fused(S):
     return l.item(), S.grad, fl.tolist()
 
 rng = np.random.default_rng(0)
-for m in (5, 16, 17, 32, 40):
+for m in (5, 16, 17, 20, 33, 40, 48, 64):
     for cond in (1e2, 1e4, 1e6, 1e8):
         S = torch.tensor(spd_batch(40, m, cond, rng), device="cuda")
         l64, g64, f64 = fused(S)
