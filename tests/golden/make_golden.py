@@ -613,6 +613,37 @@ def g7c():
     torch.set_default_dtype(torch.float32)
 
 
+def g7d():
+    """Three more samples of the same sensitivity experiment with larger perturbations of the initial filters
+    (1e-12, 1e-10, 1e-8 relative), with the per-epoch losses: does the reference itself ever end the c5 fit at a
+    different stall point?  (Round 2: re-associating two float64 sums of the GPU closure did.)"""
+    out = {}
+    torch.set_default_dtype(torch.float64)
+    stats = c2_statistics(C=100, D=3072)
+    rng = np.random.default_rng(9191)
+    path = os.path.join(HERE, "g7d_fit_c5_ensemble2.npz")
+    filters, losses, scales = [], [], []
+    for sample, scale in enumerate((1e-12, 1e-10, 1e-8)):
+        model = sqfa.model.SQFA(n_dim=3072, n_filters=16, feature_noise=0.01).double()
+        model.fit_pca(data_statistics=stats)
+        with torch.no_grad():
+            prm = model.parametrizations.filters.original
+            prm.mul_(1.0 + scale * T(rng.standard_normal(tuple(prm.shape)), torch.float64))
+        loss, _ = model.fit(data_statistics=stats, max_epochs=300, show_progress=False, return_loss=True)
+        filters.append(model.filters.detach().numpy())
+        losses.append(loss.numpy())
+        scales.append(scale)
+        print("c5 perturbed sample", sample, "scale", scale, "epochs", len(loss), "final", float(loss[-1]), flush=True)
+        out["sqfa_filters"] = np.stack(filters)
+        out["sqfa_final_loss"] = np.array([l[-1] for l in losses])
+        out["sqfa_epochs"] = np.array([len(l) for l in losses])
+        out["sqfa_scales"] = np.array(scales)
+        width = max(len(l) for l in losses)
+        out["sqfa_loss"] = np.stack([np.pad(l, (0, width - len(l)), constant_values=np.nan) for l in losses])
+        np.savez_compressed(path, **out)
+    torch.set_default_dtype(torch.float32)
+
+
 # ---------------------------------------------------------------- G3b: transform_scatters at BASELINE shapes
 def g3b():
     """The reference's transform_scatters / transform (src/sqfa/model.py:172-237, conjugate_matrix
