@@ -71,3 +71,40 @@ def test_random_case(m, nA, nB, sqrt_mode, weighted, shards, f64):
         assert rel_err(gB.cpu(), gB_ref) <= gtol
     if shards == 1:
         assert np.abs(D.cpu().numpy() - D_ref).max() <= (1e-9 if f64 else 5e-5) * max(1.0, D_ref.max())
+
+
+@pytest.mark.parametrize("K,embed", [(16, True), (16, False), (32, True), (8, True)])
+def test_many_random_filter_draws_f32_vs_f64(K, embed):
+    """Rare-event guard: the float32 kernel against the float64 kernel on the SQFA / SecondMomentsSQFA feature matrices
+    of many random filter draws (C=300 classes: ~45 000 pairs per draw).  A kernel variant tried in round 2 passed
+    every other test and still returned ONE wrong pair in ~90 000 for about one draw in a hundred
+    (tools/lodger_check.py); the loss of such a draw is off by 2e-4, sound draws agree to ~2e-7."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import model_cases as mc
+    from sqfa_amd import _native
+    C, D = 300, 64
+    stats = {k: v.to("cuda:0") for k, v in mc.c2_statistics(C=C, D=D).items()}
+    P = C * (C - 1) // 2
+    m = K + 1 if embed else K
+    worst = 0.0
+    for seed in range(120 if K <= 16 else 25):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        F = torch.randn(K, D, generator=g, dtype=torch.float64).to("cuda:0")
+        F = F / F.norm(dim=1, keepdim=True)
+        S = torch.einsum("kd,cde,le->ckl", F, stats["covariances"].double(), F) + 0.01 * torch.eye(K, device="cuda:0", dtype=torch.float64)
+        mu = stats["means"].double() @ F.T
+        if embed:
+            E = torch.zeros(C, m, m, dtype=torch.float64, device="cuda:0")
+            E[:, :K, :K] = S + mu[:, :, None] * mu[:, None, :]
+            E[:, :K, K] = mu
+            E[:, K, :K] = mu
+            E[:, K, K] = 1
+        else:
+            E = S + mu[:, :, None] * mu[:, None, :]
+        l64, f64 = _native.PairwiseLoss.apply(E, 0.5, 1e-6, True, -1.0 / P, (0, 1), None)
+        l32, f32 = _native.PairwiseLoss.apply(E.float(), 0.5, 1e-6, True, -1.0 / P, (0, 1), None)
+        assert f64.tolist() == [0, 0] and f32.tolist() == [0, 0]
+        worst = max(worst, abs(l32.item() - l64.item()) / abs(l64.item()))
+    print(f"K={K} embed={embed}: worst relative loss difference float32 vs float64 over the draws {worst:.2e}")
+    assert worst < 3e-6
