@@ -77,7 +77,10 @@ __global__ __launch_bounds__(64 * WAVES) void project_kernel(const T* __restrict
     if (chunk + 1 < nchunks) stage(chunk + 1, buf ^ 1);
     if (active) {
       const int kbase = chunk * KC;
-#pragma unroll 8
+#ifndef SQFA_PROJ_UNROLL
+#define SQFA_PROJ_UNROLL 8
+#endif
+#pragma unroll SQFA_PROJ_UNROLL
       for (int s = 0; s < KC / 4; ++s) {
         int k = kbase + 4 * s + q;
         if (k > D - 1) k = D - 1;  // past the end: F is zero there, any finite row will do
