@@ -32,6 +32,10 @@ bool sqfa_profile_enabled();                                            // sqfa_
 std::vector<std::pair<hipEvent_t, hipEvent_t>>& sqfa_project_events();  // sqfa_api.hip
 std::mutex& sqfa_project_events_mutex();                                 // sqfa_api.hip
 
+#ifndef SQFA_PROJ_VEC_STORE
+#define SQFA_PROJ_VEC_STORE 1
+#endif
+
 namespace sqfa {
 
 template <typename T, int NB, int KC, int WAVES>
@@ -109,6 +113,19 @@ __global__ __launch_bounds__(64 * WAVES) void project_kernel(const T* __restrict
       const int d = d0 + j;
       if (d < D) {
         T* out = Tout + ((size_t)c * D + d) * K;
+        if constexpr (sizeof(T) == 4) {
+          // float32: the four accumulator registers of a lane are T[d][4q .. 4q+3], one 16-byte store when K % 4 == 0
+          // (T_out rows are then 16-byte aligned); 16 scattered 4-byte stores per lane otherwise
+          const int n0 = nb * 16 + 4 * q;
+          if ((K & 3) == 0 && (reinterpret_cast<size_t>(Tout) & 15) == 0 && SQFA_PROJ_VEC_STORE) {
+            if (n0 < K) {
+              struct alignas(16) V4 { T v[4]; };
+              V4 o = {{acc[nb][j][0], acc[nb][j][1], acc[nb][j][2], acc[nb][j][3]}};
+              *reinterpret_cast<V4*>(out + n0) = o;
+            }
+            continue;
+          }
+        }
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const int n = nb * 16 + Tr::acc_row(q, reg);
@@ -141,7 +158,10 @@ template <typename T>
 static void launch_project(const T* f, const T* p, T* t, int C, int D, int K, hipStream_t stream) {
   constexpr int SW = 16 * ProjTraits<T>::VW;
   const int nstripes = (D + SW - 1) / SW;
-  if (nstripes <= 16) launch_project_w<T, 16>(f, p, t, C, D, K, stream);
+#ifndef SQFA_PROJ_WV_SMALL
+#define SQFA_PROJ_WV_SMALL 16
+#endif
+  if (nstripes <= 16) launch_project_w<T, SQFA_PROJ_WV_SMALL>(f, p, t, C, D, K, stream);
   else if (nstripes <= 32) launch_project_w<T, 8>(f, p, t, C, D, K, stream);
   else launch_project_w<T, 4>(f, p, t, C, D, K, stream);
 }

@@ -15,4 +15,4 @@ def run(C, D, K, reps=30):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     print(f"C={C} D={D} K={K}: {ms:.3f} ms = {4.0*C*D*D/ms/1e6:.0f} GB/s", flush=True)
-run(1000, 784, 16); run(1000, 2048, 32); run(100, 3072, 16)
+run(1000, 784, 16); run(1000, 2048, 32); run(100, 3072, 16); run(1000, 784, 4); run(1000, 1024, 16); run(1000, 512, 8)
