@@ -7,7 +7,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsqfa_hip.so")
+# SQFA_HIP_LIBRARY selects another build of the same library (development: A/B timing of kernel variants,
+# tools/build_variant.sh) without touching the installed file.
+LIB_PATH = os.environ.get("SQFA_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libsqfa_hip.so")
 
 SQFA_F32, SQFA_F64 = 0, 1
 SQFA_OK = 0

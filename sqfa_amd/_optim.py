@@ -104,6 +104,19 @@ def _n_classes(data_statistics):
     return data_statistics.shape[0]
 
 
+# Sharded fits: once per epoch the ranks compare a checksum of their parameters (parallel.replicas_agree: one
+# all-reduce of two integers).  If they ever differ -- an all-reduce that did not return the same bits to every
+# rank -- rank 0's parameters are broadcast again and every rank restarts its LBFGS history, with a warning.
+REPLICA_CHECK = True
+
+
+def _sharded_group(model):
+    shard = getattr(model, "pair_shard", None) or getattr(model, "class_shard", None)
+    if shard is None or getattr(shard, "world_size", 1) <= 1:
+        return None, False
+    return getattr(shard, "group", None), True
+
+
 def _broadcast_replicated_state(model):
     """Multi-GPU fits assume bit-identical filters on every rank (each rank evaluates its tile
     shard of the SAME feature scatters, and every rank repeats the same LBFGS update on the
@@ -121,95 +134,35 @@ def _broadcast_replicated_state(model):
             dist.broadcast(t.data, src=src, group=group)
 
 
-def fitting_loop(model, data_statistics, max_epochs=200, lr=0.1, atol=1e-6, show_progress=True,
-                 return_loss=False, **kwargs):
-    """Learn the filters with LBFGS.  Same arguments, stopping rule (|dloss| < atol for three
-    consecutive epochs), messages and return value as the reference's fitting_loop
-    (src/sqfa/_optim.py:33-145); extra keyword arguments go to torch.optim.LBFGS."""
-    _broadcast_replicated_state(model)
-    device_params = list(model.parameters())
-    # the compact form is four (history x n) matrix-vector products per iteration: on the host
-    # only while they are a fraction of a millisecond, otherwise on the device
-    if not COMPACT_LBFGS:
-        host_limit = HOST_SIDE_LBFGS_MAX_NUMEL
-    elif kwargs.get("line_search_fn") is not None:
-        host_limit = HOST_SIDE_LBFGS_MAX_NUMEL_LINE_SEARCH
-    else:
-        host_limit = HOST_SIDE_LBFGS_MAX_NUMEL_COMPACT
-    use_host = (HOST_SIDE_LBFGS and len(device_params) > 0 and all(p.is_cuda for p in device_params)
-                and sum(p.numel() for p in device_params) <= host_limit)
-    if use_host:
-        opt_params = [torch.nn.Parameter(p.detach().cpu().clone()) for p in device_params]
-    else:
-        opt_params = device_params
-    if COMPACT_LBFGS:
-        from ._lbfgs import CompactLBFGS
-        optimizer = CompactLBFGS(opt_params, lr=lr, **kwargs)
-    else:
-        optimizer = torch.optim.LBFGS(opt_params, lr=lr, **kwargs)
+class ShardedClosure:
+    """One closure evaluation of a sharded (multi-GPU) fit as captured HIP graphs around the collectives.
 
-    def push_parameters():
-        if use_host:
-            with torch.no_grad():
-                for p, h in zip(device_params, opt_params):
-                    p.copy_(h, non_blocking=True)
-    prepared = model._prepare_statistics(data_statistics)
-    n_classes = model._n_classes_total(prepared) if hasattr(model, "_n_classes_total") else _n_classes(data_statistics)
-    if n_classes < 2:
-        raise ValueError("At least two classes are needed to fit the filters.")  # SURVEY.md Q8
-    rows, cols = torch.tril_indices(n_classes, n_classes, offset=-1)
+    pair tiles over ranks (PairShard):  graph A = parametrization -> projection -> pair kernels -> fused buffer
+      [loss, nan, inf, dL/dS];  ONE all-reduce (eager: RCCL and gloo alike);  graph B = backward -> packed
+      [loss, nan, inf, grad];  the caller makes ONE device-to-host copy per closure.
+    + class-sharded statistics (ClassShard, large D: BASELINE config 4):  graph A1 = parametrization -> projection
+      of the LOCAL classes into their slice of the (C,m,m) batch;  all-gather of the slices;  graph A2 = pair
+      kernels -> fused buffer;  all-reduce;  graph B = backward of the local classes;  all-reduce of the filter
+      gradient;  graph C = packing.
+    Needs the single-node closure's conditions (model._single_node_inputs); other sharded fits stay eager.
+    Used by fitting_loop and, directly, by bench.py's N > 1 closure leg."""
 
-    def evaluate():
-        """Enqueue loss and gradient on the device: (loss, flags or None); no host sync."""
-        fused = model._fused_closure_loss(prepared)
-        if fused is not None:
-            loss, flags = fused
-        else:
-            if getattr(model, "class_shard", None) is not None:
-                raise NotImplementedError("class-sharded statistics need one of the native distance operators")
-            distances = model.get_class_distances(prepared, regularized=True)
-            check_distances_valid(distances)
-            loss = -distances[rows.to(distances.device), cols.to(distances.device)].mean()
-            flags = None
-        loss.backward()
-        if hasattr(model, "_sync_gradients"):
-            model._sync_gradients()
-        return loss.detach(), flags
+    @staticmethod
+    def supported(model, prepared):
+        params = list(model.parameters())
+        return bool(GRAPH_CLOSURE and len(params) == 1 and params[0].is_cuda
+                    and getattr(model, "pair_shard", None) is not None and model.pair_shard.world_size > 1
+                    and hasattr(model, "_has_fused_closure") and model._has_fused_closure()
+                    and hasattr(model, "_single_node_inputs")
+                    and model._single_node_inputs(prepared, allow_class_shard=True) is not None
+                    and model._noise_scalar() is not None)
 
-    def pack(loss, flags):
-        """[loss, nan, inf, grad...] in one device tensor: a single copy brings it to the host."""
-        dtype = loss.dtype
-        head = [loss.reshape(1), flags.to(dtype) if flags is not None else loss.new_zeros(2)]
-        return torch.cat(head + [p.grad.reshape(-1).to(dtype) for p in device_params])
+    def __init__(self, model, prepared):
+        self.state, self.calls, self.graphs = "warmup", 0, None
+        self.stages, self.box = self._build(model, prepared)
 
-    def unpack_to_host(packed):
-        host = packed.cpu()  # the only synchronisation of the closure
-        raise_on_flags(host[1:3].round().to(torch.int32))
-        offset = 3
-        for p, h in zip(device_params, opt_params):
-            n = p.numel()
-            h.grad = host[offset:offset + n].view_as(h).to(h.dtype)
-            offset += n
-        return host[0]
-
-    # ---- sharded fits: captured graphs around the collectives -----------------------------------------
-    # pair tiles over ranks (PairShard):  graph A  = parametrization -> projection -> pair kernels -> fused
-    #   buffer [loss, nan, inf, dL/dS];  ONE all-reduce (eager: RCCL and gloo alike);  graph B = backward ->
-    #   packed [loss, nan, inf, grad];  ONE device-to-host copy per closure.
-    # + class-sharded statistics (ClassShard, large D):  graph A1 = parametrization -> projection of the LOCAL
-    #   classes into their slice of the (C,m,m) batch;  all-gather of the slices;  graph A2 = pair kernels ->
-    #   fused buffer;  all-reduce;  graph B = backward of the local classes;  all-reduce of the filter gradient.
-    # Needs the single-node closure's conditions (model._single_node_inputs); other sharded fits stay eager.
-    split = {"state": "off", "calls": 0}
-    if (GRAPH_CLOSURE and len(device_params) == 1 and device_params[0].is_cuda
-            and getattr(model, "pair_shard", None) is not None and model.pair_shard.world_size > 1
-            and hasattr(model, "_has_fused_closure") and model._has_fused_closure()
-            and hasattr(model, "_single_node_inputs")
-            and model._single_node_inputs(prepared, allow_class_shard=True) is not None
-            and model._noise_scalar() is not None):
-        split["state"] = "warmup"
-
-    def split_stages():
+    @staticmethod
+    def _build(model, prepared):
         """Stage functions over static tensors, for eager warm-up and capture."""
         from . import _native, distances
         import torch.distributed as dist
@@ -266,11 +219,10 @@ def fitting_loop(model, data_statistics, max_epochs=200, lr=0.1, atol=1e-6, show
 
         return [stage_project, gather, stage_pairs, reduce, stage_backward, reduce_grad, stage_pack], box
 
-    def capture_split():
-        stages, box = split["stages"]
+    def _capture(self):
         graphs = []
         pool = None
-        for i, stage in enumerate(stages):
+        for i, stage in enumerate(self.stages):
             if i % 2 == 1:          # the collectives stay eager
                 stage()
                 graphs.append(None)
@@ -280,31 +232,110 @@ def fitting_loop(model, data_statistics, max_epochs=200, lr=0.1, atol=1e-6, show
                 stage()
             pool = g.pool()
             graphs.append(g)
-        split.update(graphs=graphs, state="on")
+        self.graphs, self.state = graphs, "on"
 
-    def split_closure(defer=False):
-        push_parameters()
-        if split.get("stages") is None:
-            split["stages"] = split_stages()
-        stages, box = split["stages"]
-        if split["state"] == "warmup" and split["calls"] >= GRAPH_WARMUP_CLOSURES:
+    def run(self):
+        """Enqueue one evaluation; returns (packed [loss, nan, inf, grad...], grad) as device tensors, no host sync."""
+        if self.state == "warmup" and self.calls >= GRAPH_WARMUP_CLOSURES:
             try:
-                capture_split()
+                self._capture()
             except Exception as err:
                 warnings.warn(f"sqfa_amd: HIP graph capture of the sharded closure failed ({err}); running eagerly")
-                split["state"] = "eager"
-        if split["state"] == "on":
-            for stage, g in zip(stages, split["graphs"]):
+                self.state = "eager"
+        if self.state == "on":
+            for stage, g in zip(self.stages, self.graphs):
                 if g is None:
                     stage()
                 else:
                     g.replay()
         else:
-            split["calls"] += 1
-            for stage in stages:
+            self.calls += 1
+            for stage in self.stages:
                 stage()
-        packed = box["packed"]
-        device_params[0].grad = box["grad"]
+        return self.box["packed"], self.box["grad"]
+
+
+def fitting_loop(model, data_statistics, max_epochs=200, lr=0.1, atol=1e-6, show_progress=True,
+                 return_loss=False, **kwargs):
+    """Learn the filters with LBFGS.  Same arguments, stopping rule (|dloss| < atol for three
+    consecutive epochs), messages and return value as the reference's fitting_loop
+    (src/sqfa/_optim.py:33-145); extra keyword arguments go to torch.optim.LBFGS."""
+    _broadcast_replicated_state(model)
+    device_params = list(model.parameters())
+    # the compact form is four (history x n) matrix-vector products per iteration: on the host
+    # only while they are a fraction of a millisecond, otherwise on the device
+    if not COMPACT_LBFGS:
+        host_limit = HOST_SIDE_LBFGS_MAX_NUMEL
+    elif kwargs.get("line_search_fn") is not None:
+        host_limit = HOST_SIDE_LBFGS_MAX_NUMEL_LINE_SEARCH
+    else:
+        host_limit = HOST_SIDE_LBFGS_MAX_NUMEL_COMPACT
+    use_host = (HOST_SIDE_LBFGS and len(device_params) > 0 and all(p.is_cuda for p in device_params)
+                and sum(p.numel() for p in device_params) <= host_limit)
+    if use_host:
+        opt_params = [torch.nn.Parameter(p.detach().cpu().clone()) for p in device_params]
+    else:
+        opt_params = device_params
+    def new_optimizer():
+        if COMPACT_LBFGS:
+            from ._lbfgs import CompactLBFGS
+            return CompactLBFGS(opt_params, lr=lr, **kwargs)
+        return torch.optim.LBFGS(opt_params, lr=lr, **kwargs)
+
+    optimizer = new_optimizer()
+    shard_group, sharded = _sharded_group(model)
+
+    def push_parameters():
+        if use_host:
+            with torch.no_grad():
+                for p, h in zip(device_params, opt_params):
+                    p.copy_(h, non_blocking=True)
+    prepared = model._prepare_statistics(data_statistics)
+    n_classes = model._n_classes_total(prepared) if hasattr(model, "_n_classes_total") else _n_classes(data_statistics)
+    if n_classes < 2:
+        raise ValueError("At least two classes are needed to fit the filters.")  # SURVEY.md Q8
+    rows, cols = torch.tril_indices(n_classes, n_classes, offset=-1)
+
+    def evaluate():
+        """Enqueue loss and gradient on the device: (loss, flags or None); no host sync."""
+        fused = model._fused_closure_loss(prepared)
+        if fused is not None:
+            loss, flags = fused
+        else:
+            if getattr(model, "class_shard", None) is not None:
+                raise NotImplementedError("class-sharded statistics need one of the native distance operators")
+            distances = model.get_class_distances(prepared, regularized=True)
+            check_distances_valid(distances)
+            loss = -distances[rows.to(distances.device), cols.to(distances.device)].mean()
+            flags = None
+        loss.backward()
+        if hasattr(model, "_sync_gradients"):
+            model._sync_gradients()
+        return loss.detach(), flags
+
+    def pack(loss, flags):
+        """[loss, nan, inf, grad...] in one device tensor: a single copy brings it to the host."""
+        dtype = loss.dtype
+        head = [loss.reshape(1), flags.to(dtype) if flags is not None else loss.new_zeros(2)]
+        return torch.cat(head + [p.grad.reshape(-1).to(dtype) for p in device_params])
+
+    def unpack_to_host(packed):
+        host = packed.cpu()  # the only synchronisation of the closure
+        raise_on_flags(host[1:3].round().to(torch.int32))
+        offset = 3
+        for p, h in zip(device_params, opt_params):
+            n = p.numel()
+            h.grad = host[offset:offset + n].view_as(h).to(h.dtype)
+            offset += n
+        return host[0]
+
+    # ---- sharded fits: captured graphs around the collectives (ShardedClosure below) -------------------
+    split = ShardedClosure(model, prepared) if (len(device_params) == 1 and ShardedClosure.supported(model, prepared)) else None
+
+    def split_closure(defer=False):
+        push_parameters()
+        packed, grad = split.run()
+        device_params[0].grad = grad
         if use_host:
             return unpack_to_host(packed)
         if defer:
@@ -332,7 +363,7 @@ def fitting_loop(model, data_statistics, max_epochs=200, lr=0.1, atol=1e-6, show
         """defer=True (device-side optimizer state only): enqueue everything and return [loss, nan, inf] as a
         DEVICE tensor without synchronising -- CompactLBFGS reads it back together with its own decision
         scalars and then calls closure.check_flags (one host synchronisation per LBFGS iteration)."""
-        if split["state"] != "off":
+        if split is not None:
             return split_closure(defer)
         push_parameters()
         if graph["state"] == "warmup" and graph["calls"] >= GRAPH_WARMUP_CLOSURES:
@@ -381,6 +412,19 @@ def fitting_loop(model, data_statistics, max_epochs=200, lr=0.1, atol=1e-6, show
             value = optimizer.step(closure).item()
             times.append(time.time() - start)
             losses.append(value)
+            if sharded and REPLICA_CHECK:
+                from .parallel import replicas_agree
+                push_parameters()   # host-side optimizer state: compare (and, if need be, re-broadcast) the device copies
+                if not replicas_agree(device_params, shard_group):
+                    warnings.warn("sqfa_amd: the ranks of this sharded fit no longer hold identical filters (the "
+                                  "all-reduce returned different bits to different ranks); re-broadcasting rank 0's "
+                                  "filters and restarting the LBFGS history on every rank")
+                    _broadcast_replicated_state(model)
+                    if use_host:
+                        with torch.no_grad():
+                            for p_dev, h in zip(device_params, opt_params):
+                                h.copy_(p_dev.detach().cpu())
+                    optimizer = new_optimizer()
             streak = streak + 1 if abs(previous - value) < atol else 0
             previous = value
             if streak >= 3:

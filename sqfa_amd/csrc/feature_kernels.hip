@@ -192,9 +192,8 @@ __global__ __launch_bounds__(64) void feature_backward_kernel(const T* __restric
 template <typename T>
 static void launch_forward(const T* f, const T* t, T* s, int C, int D, int K, T noise, const T* means, int ld,
                            hipStream_t stream) {
-  // float32 only: float64 keeps the step-by-step contraction order the float64 trajectory goldens were recorded
-  // with (see the note in finalize_kernel, sqfa_api.hip)
-  const bool fv = sizeof(T) == 4 && (reinterpret_cast<size_t>(f) % (4 * sizeof(T))) == 0 && D >= 16;  // D % 4 == 0: every row is aligned then
+  // (float64 too since round 3: no product code path is kept only to match a chaotic trajectory golden any more)
+  const bool fv = (reinterpret_cast<size_t>(f) % (4 * sizeof(T))) == 0 && D >= 16;  // D % 4 == 0: every row is aligned then
 #define SQFA_FWD(NB_, SPLIT_, THREADS_)                                                                                     \
   if (fv)                                                                                                                   \
     hipLaunchKernelGGL((feature_scatters_kernel<T, NB_, SPLIT_, true>), dim3(C), dim3(THREADS_), 0, stream, f, t, s, D, K, \

@@ -179,10 +179,16 @@ template <int S> __device__ __forceinline__ double swizzle_xor(double v) {
 // value held by lane (lane ^ S).  S > 0: compile-time partner -- DPP quad_perm for S <= 3,
 // ds_swizzle (LDS crossbar, bit-mask mode) for 4 <= S < 32; S == 0: runtime partner `s`
 // through ds_bpermute (3x slower than ds_swizzle, tools/ubench/swizzle_rate.hip).
+#ifndef SQFA_DPP_S_MASK
+#define SQFA_DPP_S_MASK 0  // bit S set: partner lane^S (S = 7, 8, 15) through a DPP row move instead of the crossbar
+#endif
 template <int S, typename T> __device__ __forceinline__ T lane_xor(T v, int s) {
   if constexpr (S == 1) return dpp_mov<0xB1>(v);
   else if constexpr (S == 2) return dpp_mov<0x4E>(v);
   else if constexpr (S == 3) return dpp_mov<0x1B>(v);
+  else if constexpr (S == 7 && ((SQFA_DPP_S_MASK >> 7) & 1)) return dpp_mov<0x141>(v);   // row_half_mirror: l -> l ^ 7
+  else if constexpr (S == 8 && ((SQFA_DPP_S_MASK >> 8) & 1)) return dpp_mov<0x128>(v);   // row_ror:8: l -> l ^ 8
+  else if constexpr (S == 15 && ((SQFA_DPP_S_MASK >> 15) & 1)) return dpp_mov<0x140>(v);  // row_mirror: l -> l ^ 15
   else if constexpr (S == 0) return __shfl_xor(v, s, 64);
   else if constexpr (S < 32) return swizzle_xor<S>(v);
   else return __shfl_xor(v, S, 64);
@@ -301,6 +307,34 @@ __device__ __forceinline__ void rot_scaled(T no, T nr, T gh, T Dx, T Dy, T tol2,
   k = rot ? R::copysign_(T(0.5) * rh * ruu, sgn) : T(0);
 }
 
+// Inner product of two register columns with NA independent partial sums (combined pairwise at the end): one
+// accumulator makes the MR fmas one dependency chain, which two waves per SIMD (MR >= 24) do not hide.
+#ifndef SQFA_DOT_ACCS
+#define SQFA_DOT_ACCS 0  // 0: by size
+#endif
+template <typename T, int MR> constexpr int dot_accs() {
+  if (SQFA_DOT_ACCS > 0) return SQFA_DOT_ACCS;
+  return 1;
+}
+template <typename T, int MR>
+__device__ __forceinline__ T dot_cols(const T (&a)[MR], const T (&b)[MR]) {
+  using R = Real<T>;
+  constexpr int NA = dot_accs<T, MR>();
+  T acc[NA];
+#pragma unroll
+  for (int k = 0; k < NA; ++k) acc[k] = T(0);
+#pragma unroll
+  for (int r = 0; r < MR; ++r) acc[r % NA] = R::fma_(a[r], b[r], acc[r % NA]);
+  if constexpr (NA == 4) return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  else if constexpr (NA == 2) return acc[0] + acc[1];
+  else {
+    T t = acc[0];
+#pragma unroll
+    for (int k = 1; k < NA; ++k) t += acc[k];
+    return t;
+  }
+}
+
 // Sizes m = G (CPL-1) + 1 (SQFA's K+1: 17 = 4*4+1, 33 = 8*4+1) leave ONE real column in the last slot of
 // one lane of the group.  Carried through the tournament it doubles the rounds of every partner
 // (pow2ceil(CPL) = 8 instead of 4) for steps in which a single lane pair of the group does useful work.
@@ -347,9 +381,7 @@ __device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
       T rv[MR];
 #pragma unroll
       for (int r = 0; r < MR; ++r) rv[r] = lane_xor_row<S, SWZ>(x[cp][r], s, r);  // partner's slot cp
-      T gh = T(0);
-#pragma unroll
-      for (int r = 0; r < MR; ++r) gh = R::fma_(x[c][r], rv[r], gh);
+      const T gh = dot_cols<T, MR>(x[c], rv);
       const T nr1 = lane_xor<S>(nrm[cp], s);
       const T Dp = lane_xor<S>(D[cp], s);
       T u1, ru1, k1, g21;
@@ -422,13 +454,11 @@ __device__ __forceinline__ void cross_step2(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
     const int c = cs[q];
-    T gh = T(0);
     // m=16 (four waves per SIMD): the inner product + parameter chain, the latency-critical part of a
     // step, also runs at raised priority (-1.4 %; +1 % at m=17, no change at m=32: off there)
     constexpr bool PARAM_PRIO = SQFA_PARAM_PRIO != 0 && MR == 16 && CPL == 4 && sizeof(T) == 4;
     if (PARAM_PRIO) __builtin_amdgcn_s_setprio(SQFA_PARAM_PRIO);
-#pragma unroll
-    for (int r = 0; r < MR; ++r) gh = R::fma_(x[c][r], rv[q][r], gh);
+    const T gh = dot_cols<T, MR>(x[c], rv[q]);
     T u1, k1, g21;
     rot_scaled(nrm[c], nr1[q], gh, D[c], Dp[q], tol2, tie, u1, ru1[q], k1, g21, big);
     kgh[q] = k1 * gh;
@@ -515,7 +545,10 @@ __device__ __forceinline__ void cross_round_paired(T (&x)[CPL][MR], T (&nrm)[CPL
 template <typename T, int G, int MR> constexpr bool paired_steps() {
   if (!SQFA_PAIRED_STEPS) return false;
   if (sizeof(T) == 8) return SQFA_PAIRED_F64 != 0;
-  return (G == 4 && MR >= 16) || G == 8;
+#ifndef SQFA_PAIRED_G16
+#define SQFA_PAIRED_G16 0
+#endif
+  return (G == 4 && MR >= 16) || G == 8 || (SQFA_PAIRED_G16 && G == 16);
 }
 
 template <typename T, int MR, int G, int CPL, int S>
@@ -542,10 +575,15 @@ __device__ __forceinline__ void local_step2(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
   constexpr int NS = A1 >= 0 ? 2 : 1;
   constexpr int ca[2] = {A0, A1 >= 0 ? A1 : A0}, cb[2] = {B0, A1 >= 0 ? B1 : B0};
   T gh[2] = {T(0), T(0)};
+  if constexpr (dot_accs<T, MR>() > 1) {
 #pragma unroll
-  for (int r = 0; r < MR; ++r) {
+    for (int q = 0; q < NS; ++q) gh[q] = dot_cols<T, MR>(x[ca[q]], x[cb[q]]);
+  } else {
 #pragma unroll
-    for (int q = 0; q < NS; ++q) gh[q] = R::fma_(x[ca[q]][r], x[cb[q]][r], gh[q]);
+    for (int r = 0; r < MR; ++r) {
+#pragma unroll
+      for (int q = 0; q < NS; ++q) gh[q] = R::fma_(x[ca[q]][r], x[cb[q]][r], gh[q]);
+    }
   }
   T a1[2], a2[2];
 #pragma unroll
@@ -938,9 +976,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
       for (int c1 = 0; c1 < CE; ++c1) {
 #pragma unroll
         for (int c2 = c1 + 1; c2 < CE; ++c2) {
-          T gh = T(0);
-#pragma unroll
-          for (int r = 0; r < MR; ++r) gh = R::fma_(x[c1][r], x[c2][r], gh);
+          const T gh = dot_cols<T, MR>(x[c1], x[c2]);
           T u, ru, k, g2;
           rot_scaled(nrm[c1], nrm[c2], gh, D[c1], D[c2], tol2, T(1), u, ru, k, g2, big);
           const T kgh = k * gh, kg2 = k * g2;

@@ -317,32 +317,12 @@ __global__ __launch_bounds__(SQFA_K2_THREADS) void finalize_kernel(const PairPar
       n_b = p.nbi > first_b ? (p.nbi - 1 - first_b) / N + 1 : 0;
     }
     T acc = T(0);
-    if constexpr (sizeof(T) == 8) {
-      // float64 keeps the original single-chain order: the float64 trajectory goldens of the chaotic fixed-step
-      // fits (G7: the c5 configuration stalls after ten epochs, in the reference too) were recorded against it,
-      // and a different association order of these sums is enough to end that fit at a different stall point
-      // (tools/c5_golden_trace.py).  float64 is the parity path, not the throughput path.
-      if (idx < TRI && grp < NG) {
-        for (int q = grp; q < n_a + n_b; q += NG) {
-          if (q < n_a) {
-            acc += slab[(size_t)(row_start_of(bi_a) + q) * tile_stride + (size_t)pi * TRI + idx];
-          } else {
-            const int bi = first_b + (q - n_a) * N;
-            if (tile_processed(p, bi, bj_b, TI, TJ)) {
-              int slot = row_start_of(bi) + bj_b;
-              if (N > 1) {
-                const int first_in_row = ((p.shard_index - bi) % N + N) % N;
-                slot = row_start_of(bi) + (bj_b - first_in_row) / N;
-              }
-              acc += slab[(size_t)slot * tile_stride + (size_t)(TI + pj) * TRI + idx];
-            }
-          }
-        }
-      }
-    } else if (idx < TRI && grp < NG) {
+    if (idx < TRI && grp < NG) {
       // group `grp` sums every NG-th A-side tile and every NG-th B-side tile, four independent partial sums each:
       // the loads of a thread do not depend on each other, and one accumulator made the ~60 of them one chain
-      // (c3: 30 -> 17 us, m=32: 202 -> 120 us).  Fixed association order: reproducible.
+      // (c3: 30 -> 17 us, m=32: 202 -> 120 us).  Fixed association order: reproducible.  (Round 2 kept a single chain
+      // for float64 so that the chaotic c5 trajectory golden stayed matched; round 3 pins filter parity at well-posed
+      // points instead -- goldens G6c / G7e -- and float64 takes the same order as float32.)
       T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
       {
         // the q-th owned tile of block-row bi_a (bj = first_a + q N) sits in slab slot row_start + q

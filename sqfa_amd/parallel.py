@@ -10,7 +10,25 @@ performs the identical LBFGS update.
 import torch
 import torch.distributed as dist
 
-__all__ = ["PairShard", "ClassShard"]
+__all__ = ["PairShard", "ClassShard", "replicas_agree"]
+
+
+def replicas_agree(tensors, group=None):
+    """True when `tensors` are BITWISE identical on every rank of `group`.  Every rank of a sharded fit repeats the
+    same LBFGS update on the all-reduced gradient, which is only sound while the all-reduce hands every rank the
+    same bits (true for RCCL's and gloo's ring / tree reductions: one rank finishes each element and the result is
+    distributed).  This is the check that would notice if that ever stopped holding: an exact integer checksum
+    of the bit patterns, compared with one MAX all-reduce of [h, -h] (= max and -min of the checksums)."""
+    h = None
+    for t in tensors:
+        bits = t.detach().contiguous().view(torch.int32 if t.element_size() == 4 else torch.int64)
+        # position-weighted so that permuted or compensating differences do not cancel
+        w = torch.arange(1, bits.numel() + 1, dtype=torch.int64, device=bits.device)
+        part = (bits.reshape(-1).to(torch.int64) * w).sum()
+        h = part if h is None else h * 1000003 + part
+    both = torch.stack([h, -h])
+    dist.all_reduce(both, op=dist.ReduceOp.MAX, group=group)
+    return bool((both[0] == -both[1]).item())
 
 
 class PairShard:

@@ -707,6 +707,161 @@ def g6b():
     np.savez_compressed(os.path.join(HERE, "g6b_fit_c1.npz"), **out)
 
 
+# ---------------------------------------------------------------- round 3: well-posed points of the ill-posed fits
+def _early_fits(out, tag, make_model, stats, epochs_list, alt):
+    """The reference's filters after `max_epochs` = E epochs (src/sqfa/_optim.py:105-134), E small enough
+    that the fixed-step trajectory has not yet amplified rounding: the point at which "filters to 1e-5"
+    IS a property of the algorithm.  Also the same fit with the Cholesky-route distance_fun (the
+    reference's own rounding-level yardstick at that epoch)."""
+    for E in epochs_list:
+        for route, dist in (("", None), ("_cholroute", alt)):
+            model = make_model(dist)
+            model.fit_pca(data_statistics=stats)
+            if f"{tag}_init" not in out:
+                out[f"{tag}_init"] = model.filters.detach().numpy().copy()
+            loss, _ = model.fit(data_statistics=stats, max_epochs=E, show_progress=False, return_loss=True)
+            out[f"{tag}_e{E}{route}_loss"] = loss.numpy()
+            out[f"{tag}_e{E}{route}_filters"] = model.filters.detach().numpy()
+            print(tag, "epochs", E, route or "reference", "losses", loss.numpy(), flush=True)
+
+
+def g7e():
+    """BASELINE config 5 shape (C=100, n_dim=3072, n_filters=16, SQFA, float64): the reference's learned
+    filters after 3 and 5 epochs."""
+    out = {}
+    torch.set_default_dtype(torch.float64)
+    stats = c2_statistics(C=100, D=3072)
+    out["check_cov00"] = stats["covariances"][0, :4, :4].numpy()
+    path = os.path.join(HERE, "g7e_fit_c5_early.npz")
+
+    def make(dist):
+        return sqfa.model.SQFA(n_dim=3072, n_filters=16, feature_noise=0.01, distance_fun=dist).double()
+
+    _early_fits(out, "sqfa", make, stats, (3, 5), cholesky_fisher_rao)
+    torch.set_default_dtype(torch.float32)
+    np.savez_compressed(path, **out)
+
+
+def g6c():
+    """BASELINE config 1 shape (C=10, n_dim=784, n_filters=4, SQFA, float64): the reference's learned filters
+    after 5 and 15 epochs (its chaotic episode starts around epoch 21, golden G6b)."""
+    out = {}
+    torch.set_default_dtype(torch.float64)
+    stats = c2_statistics(C=10, D=784)
+    out["check_cov00"] = stats["covariances"][0, :4, :4].numpy()
+
+    def make(dist):
+        return sqfa.model.SQFA(n_dim=784, n_filters=4, feature_noise=0.01, distance_fun=dist).double()
+
+    _early_fits(out, "sqfa", make, stats, (5, 15), cholesky_fisher_rao)
+    torch.set_default_dtype(torch.float32)
+    np.savez_compressed(os.path.join(HERE, "g6c_fit_c1_early.npz"), **out)
+
+
+def g4d():
+    """rotated_classes_dataset, K=4, three epochs (the 'flat' case of G4): the reference's own spread at that
+    point -- Cholesky-route distance_fun and 8 fits from 1e-14-perturbed initial filters."""
+    out = {}
+    torch.set_default_dtype(torch.float64)
+    rot = rotated_classes_dataset().double()
+    stats = {"means": torch.zeros(5, 8), "covariances": rot}
+    rng = np.random.default_rng(4444)
+    for model_name in ("smsqfa", "sqfa"):
+        cls = sqfa.model.SQFA if model_name == "sqfa" else sqfa.model.SecondMomentsSQFA
+        alt = cholesky_fisher_rao if model_name == "sqfa" else cholesky_affine_invariant
+        model = cls(n_dim=8, n_filters=4, feature_noise=1e-2, distance_fun=alt).double()
+        model.fit_pca(data_statistics=stats)
+        loss, _ = model.fit(data_statistics=stats, max_epochs=3, show_progress=False, return_loss=True)
+        out[f"rot_{model_name}_K4_e3_cholroute_loss"] = loss.numpy()
+        out[f"rot_{model_name}_K4_e3_cholroute_filters"] = model.filters.detach().numpy()
+        filters, losses = [], []
+        for sample in range(8):
+            model = cls(n_dim=8, n_filters=4, feature_noise=1e-2).double()
+            model.fit_pca(data_statistics=stats)
+            with torch.no_grad():
+                prm = model.parametrizations.filters.original
+                prm.mul_(1.0 + 1e-14 * T(rng.standard_normal(tuple(prm.shape)), torch.float64))
+            loss, _ = model.fit(data_statistics=stats, max_epochs=3, show_progress=False, return_loss=True)
+            filters.append(model.filters.detach().numpy())
+            losses.append(loss.numpy())
+        out[f"rot_{model_name}_K4_e3_ensemble_filters"] = np.stack(filters)
+        out[f"rot_{model_name}_K4_e3_ensemble_loss"] = np.stack(losses)
+        print(model_name, "ensemble losses", np.stack(losses)[:, -1], flush=True)
+    torch.set_default_dtype(torch.float32)
+    np.savez_compressed(os.path.join(HERE, "g4d_fit_rot_spread.npz"), **out)
+
+
+def g3o():
+    """G3 for constraint="orthogonal" (src/sqfa/model.py:416-431 -> torch.nn.utils.parametrizations.orthogonal),
+    reproducible this time: the parametrization's random `base` buffer is stored, and the raw parameter is of
+    the form the parametrization itself produces and trains (diagonal -1 as returned by its right_inverse, the
+    reflector entries random) -- G3's plain-random raw parameters had a diagonal that truncates to 0 in the
+    Householder map, which made the reference return NaN gradients."""
+    rng = np.random.default_rng(3030)
+    out = {}
+    rot = rotated_classes_dataset().double().numpy()
+    out["rotated_cov"] = rot
+    mu_rot = 0.2 * rng.standard_normal((rot.shape[0], rot.shape[1]))
+    out["rotated_mu"] = mu_rot
+    for K in (1, 2, 3, 4, 8):
+        raw = 0.4 * rng.standard_normal((K, 8))
+        raw[np.arange(K), np.arange(K)] = -1.0
+        out[f"raw_filters_K{K}"] = raw
+    for model_name in ("smsqfa", "sqfa"):
+        for noise in (1e-3, 1e-2):
+            for K in (1, 2, 3, 4, 8):
+                for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+                    torch.set_default_dtype(dt)
+                    torch.manual_seed(1000 * K + int(noise * 1e4))
+                    cls = sqfa.model.SQFA if model_name == "sqfa" else sqfa.model.SecondMomentsSQFA
+                    model = cls(n_dim=8, n_filters=K, feature_noise=noise, constraint="orthogonal")
+                    if dt == torch.float64:
+                        model = model.double()
+                    key = f"{model_name}_orthogonal_n{noise:g}_K{K}"
+                    par = model.parametrizations.filters[0]
+                    base_key = f"{key}_base"
+                    if base_key in out:       # float32 run: the float64 run's base, rounded
+                        par.base = T(out[base_key], dt)
+                    else:
+                        out[base_key] = par.base.detach().double().numpy().copy()
+                        out[f"{key}_map"] = np.array(par.orthogonal_map.value if hasattr(par.orthogonal_map, "value") else -1)
+                    with torch.no_grad():
+                        prm = model.parametrizations.filters.original
+                        prm.copy_(T(out[f"raw_filters_K{K}"], dt))
+                    stats = {"means": T(mu_rot, dt), "covariances": T(rot, dt)}
+                    inp = stats if model_name == "sqfa" else T(rot, dt)
+                    try:
+                        D_ = model.get_class_distances(inp, regularized=True)
+                    except Exception as err:
+                        print("  skipped", key, tag, type(err).__name__)
+                        continue
+                    loss = tril_loss(D_)
+                    model.zero_grad()
+                    loss.backward()
+                    out[f"{key}_filters_{tag}"] = model.filters.detach().numpy()
+                    out[f"{key}_D_{tag}"] = D_.detach().numpy()
+                    out[f"{key}_loss_{tag}"] = loss.detach().numpy()
+                    out[f"{key}_grad_{tag}"] = prm.grad.detach().numpy()
+                    print(key, tag, "loss", float(loss), "finite grad", bool(torch.isfinite(prm.grad).all()), flush=True)
+    # a short orthogonal fit (three epochs, float64): trajectory and learned filters
+    torch.set_default_dtype(torch.float64)
+    for model_name in ("smsqfa", "sqfa"):
+        cls = sqfa.model.SQFA if model_name == "sqfa" else sqfa.model.SecondMomentsSQFA
+        torch.manual_seed(77)
+        model = cls(n_dim=8, n_filters=3, feature_noise=1e-2, constraint="orthogonal").double()
+        key = f"{model_name}_orthogonal_fit_K3"
+        out[f"{key}_base"] = model.parametrizations.filters[0].base.detach().numpy().copy()
+        out[f"{key}_raw"] = model.parametrizations.filters.original.detach().numpy().copy()
+        out[f"{key}_init"] = model.filters.detach().numpy().copy()
+        stats = {"means": T(mu_rot, torch.float64), "covariances": T(rot, torch.float64)}
+        loss, _ = model.fit(data_statistics=stats, max_epochs=3, show_progress=False, return_loss=True)
+        out[f"{key}_loss"] = loss.numpy()
+        out[f"{key}_filters"] = model.filters.detach().numpy()
+        print(key, loss.numpy(), flush=True)
+    torch.set_default_dtype(torch.float32)
+    np.savez_compressed(os.path.join(HERE, "g3o_closure_orthogonal.npz"), **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g1x", "g2", "g3", "g4", "g5"]
     for name in which:

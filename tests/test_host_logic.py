@@ -31,6 +31,22 @@ def test_closure_matches_reference(key):
     mc.check_closure(key, torch.float64, CPU, tol_loss=1e-10, tol_grad=1e-7, tol_dist=1e-9)
 
 
+@pytest.mark.parametrize("key", mc.G3O_KEYS)
+def test_orthogonal_closure_matches_reference(key):
+    """constraint="orthogonal" (reference src/sqfa/model.py:416-431) with the parametrization's stored `base`."""
+    mc.check_closure(key, torch.float64, CPU, tol_loss=1e-10, tol_grad=1e-7, tol_dist=1e-9, G3=mc.G3O)
+
+
+def test_c1_config_early_epochs_filters_match_reference():
+    """BASELINE config 1 shape, five epochs: learned filters to 1e-5 (host logic + oracle backend)."""
+    mc.check_early_epochs("g6c_fit_c1_early.npz", 10, 784, 4, 5, CPU)
+
+
+@pytest.mark.parametrize("model_name", ["smsqfa", "sqfa"])
+def test_orthogonal_fit_matches_reference(model_name):
+    mc.check_orthogonal_fit(model_name, CPU)
+
+
 @pytest.mark.parametrize("dname", ["rot", "syn"])
 @pytest.mark.parametrize("model_name", ["smsqfa", "sqfa"])
 @pytest.mark.parametrize("K,noise", [(2, 1e-3), (4, 1e-2)])
@@ -38,10 +54,13 @@ def test_closure_matches_reference(key):
 def test_short_fit_trajectories(dname, model_name, K, noise, epochs):
     # losses come back as a float32 tensor (default dtype, like the reference) -> 1e-6.
     # rot/K=4 sits on the flat orbit F -> G F of the AIRM loss (SURVEY.md 7 "hard parts"; the
-    # reference's own float32 run diverges there): only its losses are compared.
-    flat = dname == "rot" and K == 4 and epochs > 1
-    mc.check_fit(dname, model_name, K, noise, epochs, CPU, tol_loss=1e-4 if flat else 1e-6,
-                 tol_filters=1.0 if flat else 1e-7)
+    # reference's own float32 run diverges there): bounds = 2 x the reference's own spread under
+    # rounding-level perturbations at that point (golden G4D).
+    tol_loss, tol_filters = 1e-6, 1e-7
+    if dname == "rot" and K == 4 and epochs > 1:
+        spread_f, spread_l = mc.rot_k4_spread(model_name)
+        tol_loss, tol_filters = max(1e-6, 2 * spread_l), max(1e-7, 2 * spread_f)
+    mc.check_fit(dname, model_name, K, noise, epochs, CPU, tol_loss=tol_loss, tol_filters=tol_filters)
 
 
 @pytest.mark.parametrize("model_name", ["smsqfa", "sqfa"])

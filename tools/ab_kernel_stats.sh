@@ -4,9 +4,8 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
 specs=$1; shift
-cp sqfa_amd/lib/libsqfa_hip.so /tmp/orig_lib.so
 for lib in "$@"; do
-  cp $lib sqfa_amd/lib/libsqfa_hip.so
+  export SQFA_HIP_LIBRARY=$(realpath $lib)   # read by sqfa_amd/_lib.py: the installed library stays untouched
   name=$(basename $lib .so)
   rm -rf gpurun_out/ab_$name
   SQFA_REPS=30 rocprofv3 --kernel-trace --stats -d gpurun_out/ab_$name -o s --output-format csv -- python3 tools/run_pairs_once.py $specs > gpurun_out/ab_$name.log 2>&1
@@ -20,4 +19,3 @@ for f in glob.glob("gpurun_out/ab_$name/**/s_kernel_stats.csv", recursive=True):
             print(f'{n[:70]:70s} calls {row["Calls"]:>5s} avg_us {float(row["AverageNs"])/1e3:9.2f}')
 PY
 done
-cp /tmp/orig_lib.so sqfa_amd/lib/libsqfa_hip.so

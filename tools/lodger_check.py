@@ -28,6 +28,5 @@ if sys.argv[1] == "child":
     print("worst", worst, flush=True)
 else:
     for lib in sys.argv[1:]:
-        shutil.copy(lib, os.path.join(root, "sqfa_amd/lib/libsqfa_hip.so"))
         print(lib, flush=True)
-        subprocess.run([sys.executable, __file__, "child"])
+        subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, SQFA_HIP_LIBRARY=os.path.abspath(lib)))

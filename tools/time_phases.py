@@ -1,11 +1,11 @@
 """Phase ablation of the pair kernel at c3 size: forward only vs forward+backward, for the library
 given in argv[1] (build one with -DSQFA_MAX_SWEEPS=0 to take the sweeps out).  Prints ms per launch
 of the whole evaluation (K0 + K1 + K2)."""
-import os, shutil, sys, time
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-if len(sys.argv) > 1 and os.path.abspath(sys.argv[1]) != os.path.abspath("sqfa_amd/lib/libsqfa_hip.so"):
-    shutil.copy(sys.argv[1], "sqfa_amd/lib/libsqfa_hip.so")
+if len(sys.argv) > 1:
+    os.environ["SQFA_HIP_LIBRARY"] = os.path.abspath(sys.argv[1])   # read by sqfa_amd/_lib.py at import
 import torch
 from sqfa_amd import _native
 from jacobi_emulation import baseline_like

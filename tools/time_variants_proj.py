@@ -1,5 +1,7 @@
-import sys, shutil, subprocess
+"""Run tools/time_projection.py for several pre-built library variants (SQFA_HIP_LIBRARY selects each; the installed
+library is not touched)."""
+import os, subprocess, sys
 for lib in sys.argv[1:]:
-    shutil.copy(lib, "sqfa_amd/lib/libsqfa_hip.so")
-    out = subprocess.run([sys.executable, "tools/time_projection.py"], capture_output=True, text=True)
+    out = subprocess.run([sys.executable, "tools/time_projection.py"], capture_output=True, text=True,
+                         env=dict(os.environ, SQFA_HIP_LIBRARY=os.path.abspath(lib)))
     print(lib); print("\n".join(l for l in out.stdout.splitlines() if l.startswith("C=")), flush=True)
