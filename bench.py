@@ -13,9 +13,13 @@ With N > 1 every rank holds the same S, evaluates the tile shard (bi+bj) % N == 
 partial loss / flags / gradient are summed with one RCCL all-reduce per step ("strong" scaling:
 the problem is fixed, `value` is whole-job evaluations per second).
 
-Rank 0 prints ONE JSON line.  Extra objects: "roofline" (pair tile kernel, measured live with
-HIP events on the launch stream) and "cpu_baseline" (the oracle's torch-CPU port of the
-reference op sequence, timed on the host on a bounded sample).
+Rank 0 prints ONE JSON line.  Extra objects: "roofline" (pair tile kernel; its duration is measured live with
+HIP events on the launch stream in a short pass right AFTER the timed region, which itself runs with profiling
+off), "cpu_baseline" (the oracle's torch-CPU port of the reference op sequence, timed on the host on a bounded
+sample), "prewarm" (what ran before the headline's own warm-up steps), "scaling_c4_pairs" (BASELINE config 4's
+pair stage, m=32, same sharding) and "scaling_c4_closure" (config 4 end to end at every N: class-sharded
+(C,2048,2048) statistics, projection + all-gather + pair shard + all-reduce + backward + gradient all-reduce
+as four captured graphs around the three collectives); N=1 adds "closure" (metric M2 on the headline workload).
 """
 import argparse
 import contextlib
@@ -110,12 +114,15 @@ def closure_benchmark(C, D, K, model_name, device, steps, lib, with_fit=False):
     for _ in range(max(3, min(25, steps))):   # the statistics were just generated on an idle GPU: reach the sustained clock
         closure()
     torch.cuda.synchronize()
-    lib.sqfa_airm_profile(1)
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for _ in range(steps):                    # timed region: no profiling events
         loss = closure()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    lib.sqfa_airm_profile(1)                  # separate short pass with HIP events around the kernels
+    for _ in range(max(5, min(30, steps))):
+        closure()
+    torch.cuda.synchronize()
     lib.sqfa_airm_profile(0)
     ms, n = ctypes.c_double(0), ctypes.c_int(0)
     lib.sqfa_project_profile_read(ctypes.byref(ms), ctypes.byref(n))
@@ -180,6 +187,104 @@ def closure_benchmark(C, D, K, model_name, device, steps, lib, with_fit=False):
     }
     result["fit"] = fit
     return result
+
+
+def make_class_shard_statistics(C, D, lo, hi, device, seed=1234):
+    """Second-moment matrices Psi_c = Sigma_c + mu_c mu_c^T of classes [lo, hi) of the SURVEY.md 8(d) synthetic set,
+    generated ON the device that will hold them (float32).  Each chunk of 50 classes has its own generator seed, so a
+    rank produces exactly its own class shard without drawing the other ranks' classes, and the union over ranks
+    is the same data set for every N."""
+    R = min(D, 128)
+    out = torch.empty(hi - lo, D, D, device=device)
+    eye = torch.eye(D, device=device)
+    for k in range(lo // 50, (hi + 49) // 50):
+        gen = torch.Generator(device="cpu").manual_seed(seed + 1000003 * (k + 1))
+        c0, c1 = 50 * k, min(50 * k + 50, C)
+        A = (torch.randn(c1 - c0, D, R, generator=gen) / R ** 0.5)
+        mu = 0.1 * torch.randn(c1 - c0, D, generator=gen)
+        a, b = max(lo, c0), min(hi, c1)
+        if a >= b:
+            continue
+        A, mu = A[a - c0:b - c0].to(device), mu[a - c0:b - c0].to(device)
+        out[a - lo:b - lo] = A @ A.transpose(1, 2) + 0.05 * eye + mu[:, :, None] * mu[:, None, :]
+    return out
+
+
+def c4_closure_leg(world, rank, device, pair_shard, steps, lib, fence, dist):
+    """BASELINE config 4 as written: C=1000 classes, n_dim=2048, n_filters=32, the (C,D,D) statistics
+    CLASS-sharded over the ranks (each rank generates and keeps only its own C/N classes: 16.8 GB / N), one full
+    closure = sphere -> projection of the local classes -> all-gather of the (C_r,m,m) slices -> pair-tile shard ->
+    all-reduce [loss, flags, dL/dS] -> backward of the local classes -> all-reduce of dL/dF, run as four captured
+    graphs around the three collectives (sqfa_amd._optim.ShardedClosure).  N=1: the plain single-GPU closure.
+    Reports closures/s (max time over ranks) and the per-rank projection kernel against the HBM roofline."""
+    import ctypes
+    import sqfa_amd
+    from sqfa_amd._optim import ShardedClosure
+    from sqfa_amd.parallel import ClassShard
+    C = int(os.environ.get("SQFA_BENCH_C4_CLASSES", "1000"))   # rehearsals on a shared GPU shrink the class count
+    _, D, K, _ = WORKLOADS["c4"]
+    lo, hi = rank * C // world, (rank + 1) * C // world
+    t_gen = time.perf_counter()
+    local = make_class_shard_statistics(C, D, lo, hi, device)
+    torch.manual_seed(7)                                        # identical initial filters on every rank
+    model = sqfa_amd.model.SecondMomentsSQFA(n_dim=D, n_filters=K, feature_noise=0.01).to(device)
+    if world > 1:
+        model.pair_shard = pair_shard
+        model.class_shard = ClassShard(hi - lo)
+    prepared = model._prepare_statistics(local)
+    if world > 1:
+        assert ShardedClosure.supported(model, prepared), "the graphs-around-collectives closure does not apply"
+        sharded = ShardedClosure(model, prepared)
+
+        def closure(eager=False):
+            packed, _grad = sharded.run(eager)
+            return packed
+    else:
+        def closure(eager=False):
+            model.zero_grad()
+            loss, flags = model._fused_closure_loss(prepared)
+            loss.backward()
+            return torch.cat([loss.detach().reshape(1), flags.to(loss.dtype)])
+    for _ in range(6):          # three eager evaluations, the capture, two replays
+        packed = closure()
+    fence()
+    gen_seconds = time.perf_counter() - t_gen
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        packed = closure()
+    fence()
+    seconds = time.perf_counter() - t0
+    lib.sqfa_airm_profile(1)    # separate profiled pass (HIP events around project_kernel / pair_tile_kernel),
+    for _ in range(max(3, min(10, steps))):   # as plain launches: a graph replay does not repeat the event records
+        closure(True)
+    fence()
+    lib.sqfa_airm_profile(0)
+    ms, n = ctypes.c_double(0), ctypes.c_int(0)
+    lib.sqfa_project_profile_read(ctypes.byref(ms), ctypes.byref(n))
+    ms2, n2 = ctypes.c_double(0), ctypes.c_int(0)
+    lib.sqfa_airm_profile_read(ctypes.byref(ms2), ctypes.byref(n2))
+    proj_ms, pair_ms = ms.value / max(n.value, 1), ms2.value / max(n2.value, 1)
+    head = packed[:3].double()
+    if world > 1:
+        both = torch.tensor([seconds, proj_ms, pair_ms], dtype=torch.float64, device=device)
+        dist.all_reduce(both, op=dist.ReduceOp.MAX)
+        seconds, proj_ms, pair_ms = both.tolist()
+    loss, n_nan, n_inf = head.tolist()
+    assert n_nan == 0 and n_inf == 0, "non-finite distances in the c4 closure"
+    byts = 4.0 * (hi - lo) * D * D
+    gbs = byts / (proj_ms * 1e-3) / 1e9 if proj_ms > 0 else 0.0
+    return {
+        "workload": f"c4 closure: C={C} classes, n_dim={D}, n_filters={K} (m={K}), statistics class-sharded "
+                    f"({hi - lo} classes = {byts / 1e9:.2f} GB on this rank), pair tiles sharded",
+        "value": steps / seconds, "unit": "closures/s", "n_gpus": world, "steps": steps, "warmup": 6,
+        "ms_per_closure": seconds / steps * 1e3, "scaling": "strong", "loss": loss,
+        "collectives_per_closure": 3 if world > 1 else 0,
+        "graphs_per_closure": 4 if (world > 1 and sharded.state == "on") else 0,
+        "pair_kernel_ms": pair_ms,
+        "projection": {"bound": "hbm", "kernel": "project_kernel", "kernel_ms": proj_ms, "achieved": gbs, "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s per rank", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": byts},
+        "setup_seconds": gen_seconds,
+    }
 
 
 def pmc_traffic(kernel, workload, dtype):
@@ -295,6 +400,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-closure", action="store_true", help="skip the secondary full-closure measurement (N=1)")
     ap.add_argument("--no-c4-pairs", action="store_true", help="skip the second (m=32) pair workload of the scaling curve")
+    ap.add_argument("--no-c4-closure", action="store_true", help="skip the class-sharded c4 closure leg of the scaling curve")
     ap.add_argument("--fit", action="store_true", help="also time model.fit() (metric M3) inside the closure object")
     ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -369,12 +475,17 @@ def main():
         for _ in range(warmup):
             res = step()
         fence()
-        lib.sqfa_airm_profile(1)  # HIP events around the pair kernel on its launch stream (asynchronous records)
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(steps):    # the timed region: exactly K steps, profiling off
             res = step()
         fence()
         seconds = time.perf_counter() - t0
+        # kernel duration: a SEPARATE short pass with HIP events around the pair kernel on its launch stream
+        # (asynchronous records), right after the timed region -- same inputs, same clock state
+        lib.sqfa_airm_profile(1)
+        for _ in range(max(5, min(30, steps))):
+            step()
+        fence()
         lib.sqfa_airm_profile(0)
         ms_total, launches = ctypes.c_double(0), ctypes.c_int(0)
         lib.sqfa_airm_profile_read(ctypes.byref(ms_total), ctypes.byref(launches))
@@ -391,12 +502,19 @@ def main():
     # work per pair of c3, so that the per-evaluation fixed costs (launches, one all-reduce) stay small
     # against the kernel also at 8 ranks.  Same sharding, same step; every rank takes part.
     c4_pairs = None
+    prewarm = None
     S, scale = make_feature_scatters(C, D, K, model, device, dtype)   # both inputs first: no idle gap between the legs
     if args.workload != "c4" and not args.no_c4_pairs and dtype == torch.float32:
         C4, D4, K4, model4 = WORKLOADS["c4"]
         S4, scale4 = make_feature_scatters(C4, D4, K4, model4, device, dtype)
         steps4, warm4 = max(5, min(40, args.steps)), max(2, min(10, args.warmup))
+        t_pre = time.perf_counter()
         sec4, kms4, (loss4, flags4, _g4) = time_pair_workload(S4, scale4, warm4, steps4)
+        prewarm = {
+            "what": "the scaling_c4_pairs leg (C=1000, m=32 pair kernel) runs BEFORE the headline's own --warmup steps, so "
+                    "the headline is measured at the chip's sustained clock (what a fit sees), not on the ramp from idle",
+            "launches": warm4 + steps4 + max(5, min(30, steps4)), "seconds": time.perf_counter() - t_pre,
+        }
         assert flags4.tolist() == [0, 0]
         c4_pairs = {
             "workload": f"c4 pair stage: C={C4} classes, n_filters={K4} (m={S4.shape[1]}), {C4 * (C4 - 1) // 2} unordered pairs per eval",
@@ -412,6 +530,13 @@ def main():
     assert flags.tolist() == [0, 0], f"non-finite distances: {flags.tolist()}"
 
     S_cpu = S.detach().cpu() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    # BASELINE config 4 end to end (class-sharded projection + pair shard + collectives), every rank takes part
+    c4_closure = None
+    if not args.no_c4_closure and dtype == torch.float32:
+        del S, grad
+        torch.cuda.empty_cache()
+        c4_closure = c4_closure_leg(world, rank, device, shard, max(5, min(20, args.steps // 4)), lib, fence, dist)
+        torch.cuda.empty_cache()
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         evals_per_s = args.steps / elapsed
@@ -458,11 +583,12 @@ def main():
                         f"{bytes_eval / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS * 100:.3f}% of the 8 TB/s HBM roofline",
             },
         }
+        result["prewarm"] = prewarm
         if c4_pairs is not None:
             result["scaling_c4_pairs"] = c4_pairs
+        if c4_closure is not None:
+            result["scaling_c4_closure"] = c4_closure
         if not args.no_closure and world == 1 and dtype == torch.float32:
-            del S, grad
-            torch.cuda.empty_cache()
             result["closure"] = closure_benchmark(C, D, K, model, device, max(10, min(100, args.steps // 2)), lib, with_fit=args.fit)
             result["closure"]["roofline"]["traffic"] = pmc_traffic("project_kernel", args.workload, args.dtype)
             result["closure"]["roofline"]["traffic_unit"] = f"bytes per launch (profiles/{PMC_FILE})"

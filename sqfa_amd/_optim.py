@@ -234,8 +234,14 @@ class ShardedClosure:
             graphs.append(g)
         self.graphs, self.state = graphs, "on"
 
-    def run(self):
-        """Enqueue one evaluation; returns (packed [loss, nan, inf, grad...], grad) as device tensors, no host sync."""
+    def run(self, eager=False):
+        """Enqueue one evaluation; returns (packed [loss, nan, inf, grad...], grad) as device tensors, no host sync.
+        eager=True runs the stages as plain launches even after the capture (profiling passes: the library's HIP
+        event records around its kernels happen at launch time, which a graph replay does not repeat)."""
+        if eager:
+            for stage in self.stages:
+                stage()
+            return self.box["packed"], self.box["grad"]
         if self.state == "warmup" and self.calls >= GRAPH_WARMUP_CLOSURES:
             try:
                 self._capture()

@@ -222,11 +222,12 @@ def test_sharded_closure_runs_as_two_graphs_around_one_all_reduce():
 def test_bench_two_ranks_rehearsal_on_one_gpu():
     """`python bench.py --gpus 2` by itself: the launcher starts both ranks; on a
     one-GPU box they share cuda:0 over gloo (SQFA_BENCH_REHEARSAL=1).  One JSON line, n_gpus = 2, the same
-    loss as the single-process run, the c4 pair leg present."""
+    loss as the single-process run, the c4 pair leg and the class-sharded c4 closure leg present."""
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["SQFA_BENCH_REHEARSAL"] = "1"
+    env["SQFA_BENCH_C4_CLASSES"] = "60"        # the c4 closure leg (D=2048, K=32) on 60 instead of 1000 classes
     args = ["--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--workload", "c2"]
     two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, env=env,
                          capture_output=True, text=True, timeout=500)
@@ -242,3 +243,11 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert abs(r2["loss"] - r1["loss"]) < 1e-5 * abs(r1["loss"])
     assert r2["scaling_c4_pairs"]["n_gpus"] == 2 and r2["scaling_c4_pairs"]["value"] > 0
     assert r2["roofline"]["bound"] == "valu" and 0 < r2["roofline"]["frac"] < 1
+    assert "launches" in r2["prewarm"] and r2["prewarm"]["seconds"] > 0           # what ran before the headline's warm-up
+    # BASELINE config 4 end to end: class-sharded projection + pair shard, four graphs around three collectives;
+    # the union of the ranks' class shards is the same data set as the single-process run's
+    c2_, c1_ = r2["scaling_c4_closure"], r1["scaling_c4_closure"]
+    assert c2_["n_gpus"] == 2 and c2_["graphs_per_closure"] == 4 and c2_["collectives_per_closure"] == 3
+    assert c1_["n_gpus"] == 1 and c1_["collectives_per_closure"] == 0
+    assert c2_["value"] > 0 and c2_["projection"]["kernel_ms"] > 0 and 0 < c2_["projection"]["frac"] < 1
+    assert abs(c2_["loss"] - c1_["loss"]) < 2e-5 * abs(c1_["loss"])
