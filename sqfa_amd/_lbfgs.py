@@ -238,14 +238,16 @@ class CompactLBFGS(torch.optim.LBFGS):
                     elif loss_t.device == flat_grad.device:
                         packed = torch.cat([packed, loss_t.to(flat_grad.dtype).reshape(1)])
                     vals = packed.tolist()
-                    if head is not None:
-                        raw_closure.check_flags(vals[5], vals[6])  # raises like the synchronous closure would have
                     if speculate and vals[3] > -tolerance_change:
-                        # torch stops BEFORE this step: undo it, forget the extra evaluation
+                        # torch stops BEFORE this step: undo it, forget the extra evaluation -- including its
+                        # validity flags (torch.optim.LBFGS and the reference never evaluate that point, so a NaN
+                        # there must not raise)
                         self._set_param(backup)
                         flat_grad = prev_flat_grad.clone(memory_format=torch.contiguous_format)
                         loss = prev_loss
                         break
+                    if head is not None:
+                        raw_closure.check_flags(vals[5], vals[6])  # raises like the synchronous closure would have
                     g_max, step_max = vals[0], vals[1]
                     ahead = (y_next, s_next, vals[2], H_next)
                     loss = vals[4] if len(vals) > 4 else float(loss_t)

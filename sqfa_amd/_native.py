@@ -275,27 +275,43 @@ class GaussPairTerms(torch.autograd.Function):
 # projection of the class scatter matrices (the HBM-bound stage around the pair kernel)
 
 
-_symmetry_checked = {}   # (data_ptr, _version, shape, dtype) -> bool, for the scatter tensors seen most recently
+_symmetry_checked = {}   # id(tensor) -> (weakref to the tensor, _version, verdict): dies with the tensor, never reused by another
 
 
 def _is_symmetric_batch(scatters):
     """The streaming kernel forms T = Psi^T F^T, which equals the reference's Psi F^T only for
     symmetric Psi (covariance / second-moment matrices are; conjugate_matrix itself is general,
-    src/sqfa/linalg.py:19-45).  Checked ONCE per tensor identity (one pass over Psi and one host
-    read), outside any graph capture; asymmetry at rounding level (a GEMM-built X^T X) passes."""
-    key = (scatters.data_ptr(), scatters._version, tuple(scatters.shape), scatters.dtype)
-    hit = _symmetry_checked.get(key)
-    if hit is not None:
-        return hit
+    src/sqfa/linalg.py:19-45).  Checked ONCE per tensor object and version (one pass over Psi in class chunks of
+    at most ~256 MB -- the c4 statistics are 16.8 GB, whole-tensor temporaries would triple that -- and one host
+    read), outside any graph capture; asymmetry at rounding level (a GEMM-built X^T X) passes.  The verdict is
+    keyed on the tensor OBJECT (weak reference), not on its address: the caching allocator hands a freed address
+    to the next tensor.  Any failure of the check itself (e.g. out of memory) selects the general torch expression."""
+    import weakref
+    hit = _symmetry_checked.get(id(scatters))
+    if hit is not None and hit[0]() is scatters and hit[1] == scatters._version:
+        return hit[2]
     if torch.cuda.is_current_stream_capturing():
         return False  # never seen outside a capture: take the general torch expression
     tol = 1e-5 if scatters.dtype == torch.float32 else 1e-12
-    with torch.no_grad():
-        asym = (scatters - scatters.transpose(-2, -1)).abs().amax()
-        ok = bool(asym <= tol * scatters.abs().amax())
-    if len(_symmetry_checked) > 16:
-        _symmetry_checked.clear()
-    _symmetry_checked[key] = ok
+    try:
+        with torch.no_grad():
+            per_class = scatters[0].numel() * scatters.element_size()
+            step = max(1, (256 << 20) // max(per_class, 1))
+            asym = scatters.new_zeros(())
+            peak = scatters.new_zeros(())
+            for c0 in range(0, scatters.shape[0], step):
+                blk = scatters[c0:c0 + step]
+                asym = torch.maximum(asym, (blk - blk.transpose(-2, -1)).abs().amax())
+                peak = torch.maximum(peak, blk.abs().amax())
+            ok = bool(asym <= tol * peak)
+    except Exception:   # the check must never take the fit down: the torch expression handles every input
+        ok = False
+    key = id(scatters)
+    try:
+        ref = weakref.ref(scatters, lambda _r, k=key: _symmetry_checked.pop(k, None))
+    except TypeError:
+        return ok
+    _symmetry_checked[key] = (ref, scatters._version, ok)
     return ok
 
 

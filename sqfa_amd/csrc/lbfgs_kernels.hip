@@ -220,6 +220,9 @@ __global__ __launch_bounds__(256) void lb_store_rows(T* __restrict__ S, T* __res
 // (the last one is torch's H_diag for the next direction, valid when the pair is accepted).  Block partials are
 // combined in index order by the second launch: reproducible.
 constexpr int LB_STAT_BLOCKS = 256;
+// max that PROPAGATES NaN like torch's abs().max() (fmax drops it: an all-NaN gradient would read as max|g| = 0 and
+// end the step as "converged" where torch.optim.LBFGS and the reference carry the NaN on)
+template <typename T> __device__ __forceinline__ T lb_nan_max(T a, T b) { return (a != a || b != b) ? (a + b) : fmax(a, b); }
 template <typename T>
 __global__ __launch_bounds__(256) void lb_step_stats(const T* __restrict__ g, const T* __restrict__ g_prev, const T* __restrict__ d,
                                                      T t, int n, T* __restrict__ y, T* __restrict__ sv, T* __restrict__ part) {
@@ -229,8 +232,8 @@ __global__ __launch_bounds__(256) void lb_step_stats(const T* __restrict__ g, co
     const T ge = g[e], ye = ge - g_prev[e], se = t * d[e];
     y[e] = ye;
     sv[e] = se;
-    gmax = fmax(gmax, fabs(ge));
-    smax = fmax(smax, fabs(se));
+    gmax = lb_nan_max(gmax, fabs(ge));
+    smax = lb_nan_max(smax, fabs(se));
     ys += ye * se;
     yy += ye * ye;
   }
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(256) void lb_step_stats(const T* __restrict__ g, co
     s_red[threadIdx.x] = v;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
-      if (threadIdx.x < st) s_red[threadIdx.x] = fmax(s_red[threadIdx.x], s_red[threadIdx.x + st]);
+      if (threadIdx.x < st) s_red[threadIdx.x] = lb_nan_max(s_red[threadIdx.x], s_red[threadIdx.x + st]);
       __syncthreads();
     }
     const T r = s_red[0];
@@ -263,8 +266,8 @@ __global__ __launch_bounds__(64) void lb_step_stats_finish(const T* __restrict__
   if (threadIdx.x != 0) return;
   T gmax = T(0), smax = T(0), ys = T(0), yy = T(0);
   for (int b = 0; b < blocks; ++b) {
-    gmax = fmax(gmax, part[4 * b + 0]);
-    smax = fmax(smax, part[4 * b + 1]);
+    gmax = lb_nan_max(gmax, part[4 * b + 0]);
+    smax = lb_nan_max(smax, part[4 * b + 1]);
     ys += part[4 * b + 2];
     yy += part[4 * b + 3];
   }

@@ -3,8 +3,11 @@ src/sqfa/distances.py; contract: docs/source/tutorials/distances.md:127-178, 460
 
 The affine-invariant family -- ``affine_invariant[_sq]`` on SPD batches and
 ``fisher_rao_lower_bound[_sq]`` on Gaussian statistics -- is the hot path and runs on the
-hand-written HIP kernels (forward and backward).  The other operators are not defaults of
-either model and stay plain torch.
+hand-written HIP kernels (forward and backward).  The other operators (SURVEY.md 8f rank 4) are not defaults of
+either model; for GPU tensors their pair-dependent terms run on the native Gaussian pair kernel
+(``bhattacharyya`` / ``mahalanobis[_sq]`` / ``hellinger`` / ``fisher_rao_same_cov``: sqfa_gauss_pair_terms) or avoid
+the reference's (nA,nB,m,m) tensor (``log_euclidean[_sq]``: per-class logarithms + exact pairwise distances); CPU
+tensors keep the reference's torch expression.
 """
 import torch
 
@@ -128,7 +131,7 @@ def fisher_rao_lower_bound(statistics_A, statistics_B):
 
 
 # ------------------------------------------------------------------------------------------
-# operators outside the hot path: plain torch, any device
+# operators outside the hot path (GPU tensors: native Gaussian pair kernel / no pair tensor; CPU tensors: torch)
 
 
 def log_euclidean_sq(A, B):
