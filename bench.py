@@ -36,7 +36,7 @@ if ROOT not in sys.path:
 
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector == f32 MFMA dense peak
 HBM_PEAK_GBS = 8000.0
-PMC_FILE = "r2_pmc_c3.json"   # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary the `traffic` fields quote
+PMC_FILE = "r3_pmc_c3.json"   # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary the `traffic` fields quote
 
 WORKLOADS = {
     # name: (C, D, K, model)   model: "smsqfa" -> m=K, "sqfa" -> m=K+1 (Calvo-Oller embedding, scale 1/2)
@@ -458,20 +458,43 @@ def main():
         P_ = S.shape[0] * (S.shape[0] - 1) // 2
         weight = -1.0 / P_
 
-        def step():
-            # exactly what sqfa_amd._native.PairwiseLoss.forward does inside a closure
+        fused = torch.empty(S.numel() + 3, dtype=S.dtype, device=device) if world > 1 else None
+
+        def launch_shard():
+            """This rank's tile shard into the fused buffer [loss, nan, inf, dL/dS] (what PairwiseLoss.forward does)."""
+            out = _native.hip_pair_backend(S, None, scale=scale, eps=_native.EPSILON, sqrt_mode=True, weights=None,
+                                           uniform_weight=weight, shard=shard.shard, want_loss=True, want_grad=True,
+                                           want_dist=False, want_eig=False, out_loss=fused[0],
+                                           out_gradA=fused[3:].view(S.shape))
+            fused[1:3].copy_(out["nonfinite"])   # int32 -> real in the copy itself
+
+        graph = {"g": None}
+
+        def step(eager=False):
             if world > 1:
-                fused = torch.empty(S.numel() + 3, dtype=S.dtype, device=device)
-                out = _native.hip_pair_backend(S, None, scale=scale, eps=_native.EPSILON, sqrt_mode=True, weights=None,
-                                               uniform_weight=weight, shard=shard.shard, want_loss=True, want_grad=True,
-                                               want_dist=False, want_eig=False, out_loss=fused[0],
-                                               out_gradA=fused[3:].view(S.shape))
-                return shard.reduce_fused(fused, out["nonfinite"], S.shape)
+                # N > 1: the kernel launches of a step are replayed from a captured HIP graph, the all-reduce stays
+                # eager -- exactly how a sharded fit runs its closure (sqfa_amd._optim.ShardedClosure).  At 8 ranks a
+                # rank's GPU work is 0.17 ms; launched eagerly from Python the step was host-bound at 0.29 ms
+                # (tools/time_shard.py, profiles/r3_shard_timings.txt).
+                if graph["g"] is not None and not eager:
+                    graph["g"].replay()
+                else:
+                    launch_shard()
+                dist.all_reduce(fused, op=dist.ReduceOp.SUM, group=shard.group)
+                return fused[0], fused[1:3].to(torch.int32), fused[3:].view(S.shape)
             out = _native.hip_pair_backend(S, None, scale=scale, eps=_native.EPSILON, sqrt_mode=True, weights=None,
                                            uniform_weight=weight, shard=shard.shard, want_loss=True, want_grad=True,
                                            want_dist=False, want_eig=False)
             return out["loss"], out["nonfinite"], out["gradA"]
 
+        if world > 1:
+            for _ in range(2):
+                step()
+            fence()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                launch_shard()
+            graph["g"] = g
         for _ in range(warmup):
             res = step()
         fence()
@@ -481,10 +504,11 @@ def main():
         fence()
         seconds = time.perf_counter() - t0
         # kernel duration: a SEPARATE short pass with HIP events around the pair kernel on its launch stream
-        # (asynchronous records), right after the timed region -- same inputs, same clock state
+        # (asynchronous records; plain launches: a graph replay does not repeat them), right after the timed
+        # region -- same inputs, same clock state
         lib.sqfa_airm_profile(1)
         for _ in range(max(5, min(30, steps))):
-            step()
+            step(True)
         fence()
         lib.sqfa_airm_profile(0)
         ms_total, launches = ctypes.c_double(0), ctypes.c_int(0)
@@ -513,7 +537,7 @@ def main():
         prewarm = {
             "what": "the scaling_c4_pairs leg (C=1000, m=32 pair kernel) runs BEFORE the headline's own --warmup steps, so "
                     "the headline is measured at the chip's sustained clock (what a fit sees), not on the ramp from idle",
-            "launches": warm4 + steps4 + max(5, min(30, steps4)), "seconds": time.perf_counter() - t_pre,
+            "launches": warm4 + steps4 + max(5, min(30, steps4)) + (2 if world > 1 else 0), "seconds": time.perf_counter() - t_pre,
         }
         assert flags4.tolist() == [0, 0]
         c4_pairs = {
