@@ -101,13 +101,20 @@ static bool width_allowed(int nA, int nBeff, const Geometry& g, int tj, int self
   return shard_tiles(nA, nBeff, g, tj, self_mode, 0, 1) <= 16L * resident_workgroups();
 }
 
+// ... while the launch has fewer than SQFA_TILE_ROUNDS x the resident workgroups in tiles.  2 since round 3: a launch of
+// just over one round of workgroups (m <= 8 at C=1000: ~1000 tiles of 64 x 8 pairs) ends with half the chip idle for
+// one tile's duration; measured C=1000, m=8 0.218 -> 0.202 ms, m=4 likewise; sizes with >= 2 rounds are unaffected
+// (m=16 1.050 vs 1.041-1.048 ms with the narrowest tiles: within noise, and they double the A-side slab).
+#ifndef SQFA_TILE_ROUNDS
+#define SQFA_TILE_ROUNDS 2
+#endif
 // Tile width a call with `shard_count` shards uses: halved while a shard's launch would leave workgroup
 // slots empty.  Decided from the TOTAL tile count and shard_count only, so that every shard of a job
 // picks the same tiling (tile ownership (bi + bj) % shard_count is defined on that tiling).
 static int choose_tile_width(int nA, int nBeff, const Geometry& g, int self_mode, int shard_count) {
   int tj = g.TJ;
   while (tj % 2 == 0 && width_allowed(nA, nBeff, g, tj / 2, self_mode) &&
-         shard_tiles(nA, nBeff, g, tj, self_mode, 0, 1) / shard_count < resident_workgroups())
+         shard_tiles(nA, nBeff, g, tj, self_mode, 0, 1) / shard_count < (long)SQFA_TILE_ROUNDS * resident_workgroups())
     tj /= 2;
   return tj;
 }
