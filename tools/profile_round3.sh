@@ -35,4 +35,7 @@ python3 tools/time_gauss_pairs.py > $P/gauss_pairs.txt 2>&1
 python3 tools/overlap_probe.py c3 > $P/overlap_probe.txt 2>&1
 python3 tools/overlap_probe.py c4 >> $P/overlap_probe.txt 2>&1
 python3 tools/time_projection_kernel.py > $P/projection_kernel.txt 2>&1
+python3 tools/time_projection_dims.py 736 768 784 800 816 832 896 960 1024 784 > $P/projection_dims.txt 2>&1
+python3 tools/clock_probe.py 16 17 32 33 8 > $P/clock_probe.txt 2>&1
+python3 tools/scale_probe.py > $P/scale_probe.txt 2>&1
 date; echo done
