@@ -708,7 +708,7 @@ def g6b():
 
 
 # ---------------------------------------------------------------- round 3: well-posed points of the ill-posed fits
-def _early_fits(out, tag, make_model, stats, epochs_list, alt):
+def _early_fits(out, tag, make_model, stats, epochs_list, alt, **fit_kwargs):
     """The reference's filters after `max_epochs` = E epochs (src/sqfa/_optim.py:105-134), E small enough
     that the fixed-step trajectory has not yet amplified rounding: the point at which "filters to 1e-5"
     IS a property of the algorithm.  Also the same fit with the Cholesky-route distance_fun (the
@@ -719,7 +719,7 @@ def _early_fits(out, tag, make_model, stats, epochs_list, alt):
             model.fit_pca(data_statistics=stats)
             if f"{tag}_init" not in out:
                 out[f"{tag}_init"] = model.filters.detach().numpy().copy()
-            loss, _ = model.fit(data_statistics=stats, max_epochs=E, show_progress=False, return_loss=True)
+            loss, _ = model.fit(data_statistics=stats, max_epochs=E, show_progress=False, return_loss=True, **fit_kwargs)
             out[f"{tag}_e{E}{route}_loss"] = loss.numpy()
             out[f"{tag}_e{E}{route}_filters"] = model.filters.detach().numpy()
             print(tag, "epochs", E, route or "reference", "losses", loss.numpy(), flush=True)
@@ -740,6 +740,26 @@ def g7e():
     _early_fits(out, "sqfa", make, stats, (3, 5), cholesky_fisher_rao)
     torch.set_default_dtype(torch.float32)
     np.savez_compressed(path, **out)
+
+
+def g7f():
+    """BASELINE config 5 shape with line_search_fn="strong_wolfe" (LBFGS kwargs are forwarded, src/sqfa/_optim.py:78-82):
+    the reference's filters after 1 and 2 epochs (a full strong-Wolfe fit of this configuration is ~11 000 closures,
+    ~8 CPU-hours per run: golden G7b never got it; two epochs are ~500 closures)."""
+    out = {}
+    torch.set_default_dtype(torch.float64)
+    torch.set_num_threads(3)
+    stats = c2_statistics(C=100, D=3072)
+    out["check_cov00"] = stats["covariances"][0, :4, :4].numpy()
+
+    def make(dist):
+        return sqfa.model.SQFA(n_dim=3072, n_filters=16, feature_noise=0.01, distance_fun=dist).double()
+
+    path = os.path.join(HERE, "g7f_fit_c5_wolfe_early.npz")
+    for E in (1, 2):
+        _early_fits(out, "sqfa", make, stats, (E,), cholesky_fisher_rao, line_search_fn="strong_wolfe")
+        np.savez_compressed(path, **out)
+    torch.set_default_dtype(torch.float32)
 
 
 def g6c():
