@@ -452,6 +452,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    graphs_used = []   # N > 1: whether each pair workload's launches were replayed from a captured graph
+
     def time_pair_workload(S, scale, warmup, steps):
         """W untimed + K timed loss+grad evaluations of the pair workload S; returns
         (seconds for the K steps [max over ranks], pair kernel ms per launch [max over ranks], last outputs)."""
@@ -491,10 +493,17 @@ def main():
             for _ in range(2):
                 step()
             fence()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                launch_shard()
-            graph["g"] = g
+            try:
+                g = torch.cuda.CUDAGraph()
+                # thread_local: the process group's watchdog thread must not invalidate the capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    launch_shard()
+                graph["g"] = g
+            except Exception as err:   # the capture is an optimisation: keep measuring, eagerly, and say so
+                sys.stderr.write(f"bench.py: HIP graph capture of the shard launches failed ({err}); running them eagerly\n")
+                graph["g"] = None
+            graphs_used.append(graph["g"] is not None)
+            fence()
         for _ in range(warmup):
             res = step()
         fence()
@@ -590,6 +599,7 @@ def main():
             "pairs_per_s": evals_per_s * P,
             "loss": loss.item(),
             "rccl_ranks": dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else (1 if world == 1 else 0),
+            "shard_launches_from_hip_graph": bool(graphs_used and all(graphs_used)),
             "roofline": {
                 "bound": "valu",
                 "achieved": achieved_tf,

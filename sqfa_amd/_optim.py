@@ -228,7 +228,9 @@ class ShardedClosure:
                 graphs.append(None)
                 continue
             g = torch.cuda.CUDAGraph()
-            with _no_gc(), torch.cuda.graph(g, pool=pool):
+            # thread_local: the process group's watchdog thread polls its events while this thread captures; under
+            # the default "global" mode such a call from ANOTHER thread invalidates the capture
+            with _no_gc(), torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                 stage()
             pool = g.pool()
             graphs.append(g)

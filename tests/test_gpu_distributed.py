@@ -131,6 +131,62 @@ def test_rccl_backend_single_rank():
     assert np.abs(fl - G4["syn_sqfa_K2_e3_loss"]).max() < 1e-6
 
 
+def _rccl_graph_worker(port, q):
+    """Graph captures while an RCCL communicator (and its watchdog thread) is alive: what every rank of
+    `bench.py --gpus N` and of a sharded fit does.  One rank is all a one-GPU box allows; the sharded closure is
+    built directly (ShardedClosure.supported asks for more than one rank)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        import model_cases as mc
+        from sqfa_amd._optim import ShardedClosure
+        from sqfa_amd.parallel import ClassShard, PairShard
+        warm = torch.ones(8, device=dev)
+        dist.all_reduce(warm)                                   # the communicator exists from here on
+        stats = {k: v.to(dev) for k, v in mc.c2_statistics(C=24, D=96).items()}
+        results = {}
+        for class_sharded in (False, True):
+            model = mc.make_model("sqfa", 96, 4, 0.01, "sphere", torch.float64, dev)
+            model.fit_pca(data_statistics=stats)
+            model.pair_shard = PairShard()
+            if class_sharded:
+                model.class_shard = ClassShard(24)
+            prepared = model._prepare_statistics(stats)
+            closure = ShardedClosure(model, prepared)
+            outs = []
+            for _ in range(7):                                   # three eager, the capture, replays
+                packed, grad = closure.run()
+                outs.append(packed.detach().cpu().numpy().copy())
+            eager, _ = closure.run(eager=True)
+            results[class_sharded] = (closure.state, [g is not None for g in closure.graphs or []], outs, eager.cpu().numpy())
+        q.put(results)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_graph_capture_with_live_rccl_communicator():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_graph_worker, args=(27800 + os.getpid() % 2000, q))
+    p.start()
+    results = q.get(timeout=500)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    for class_sharded, (state, graphs, outs, eager) in results.items():
+        assert state == "on", f"capture failed with a live RCCL communicator (class_sharded={class_sharded})"
+        assert sum(graphs) == 4 and len(graphs) == 7           # four captured stages, three eager collectives
+        for o in outs:
+            assert np.array_equal(o, outs[0])                    # replays are bit-identical to the eager evaluations
+        assert np.array_equal(eager, outs[0])
+        assert np.isfinite(outs[0]).all() and outs[0][1] == 0 and outs[0][2] == 0
+
+
 def _split_graph_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
