@@ -34,9 +34,6 @@
 #ifndef SQFA_ROW_F32_33
 #define SQFA_ROW_F32_33(X) X(float, 33, 8, 5, 4, 1)
 #endif
-#ifndef SQFA_ROW_F32_40
-#define SQFA_ROW_F32_40(X) X(float, 40, 8, 5, 4, 1)
-#endif
 #ifndef SQFA_ROW_F32_48
 #define SQFA_ROW_F32_48(X) X(float, 48, 16, 3, 4, 1)
 #endif
@@ -54,7 +51,6 @@
   SQFA_ROW_F32_24(X) \
   SQFA_ROW_F32_32(X) \
   SQFA_ROW_F32_33(X) \
-  SQFA_ROW_F32_40(X) \
   SQFA_ROW_F32_48(X) \
   SQFA_ROW_F32_64(X)
 
@@ -76,18 +72,6 @@
 #ifndef SQFA_ROW_F64_20
 #define SQFA_ROW_F64_20(X) X(double, 20, 8, 3, 8, 4)
 #endif
-#ifndef SQFA_ROW_F64_24
-#define SQFA_ROW_F64_24(X) X(double, 24, 16, 2, 4, 1)
-#endif
-#ifndef SQFA_ROW_F64_32
-#define SQFA_ROW_F64_32(X) X(double, 32, 16, 2, 4, 1)
-#endif
-#ifndef SQFA_ROW_F64_33
-#define SQFA_ROW_F64_33(X) X(double, 33, 16, 3, 4, 1)
-#endif
-#ifndef SQFA_ROW_F64_48
-#define SQFA_ROW_F64_48(X) X(double, 48, 32, 2, 4, 1)
-#endif
 #ifndef SQFA_ROW_F64_64
 #define SQFA_ROW_F64_64(X) X(double, 64, 64, 1, 4, 2)
 #endif
@@ -99,8 +83,27 @@
   SQFA_ROW_F64_16(X) \
   SQFA_ROW_F64_17(X) \
   SQFA_ROW_F64_20(X) \
-  SQFA_ROW_F64_24(X) \
-  SQFA_ROW_F64_32(X) \
-  SQFA_ROW_F64_33(X) \
-  SQFA_ROW_F64_48(X) \
   SQFA_ROW_F64_64(X)
+
+// 2-D lane layouts (pair_kernel_2d.hpp): X(T, MR, GC, CPL, TJ, WAVES, RS) -- GC column lanes x 2 row lanes per pair, CPL
+// column slots x ceil(MR/2) rows per lane, row partner lane ^ RS.  Keep in sync with CONFIGS2D in the Makefile.
+// Used where the whole-column layout is down to ONE wave per SIMD (measured round 3, C=1000, ms per evaluation,
+// whole columns -> 2-D; profiles/r3_pairs_2d.txt):
+//   float32 m=40: 32.8 -> 19.4            float64 m=24: 13.1 -> 9.55   m=32: 36.5 -> 24.9   m=33: 52.1 -> 39.3
+//                                         float64 m=48 (C=300): 30.6 -> 10.9   [m=64 (C=300): 48.7 -> 34.9, not shipped: its
+//                                         unrolled 32-lane tournament takes 3.4 minutes to compile]
+// and NOT where the whole-column layout already holds two or more waves per SIMD -- everything per rotation is executed
+// by both row lanes (+20-27 % instructions), which more waves do not pay back:
+//   float32 m=24: 3.64 -> 4.63, m=32: 8.55-8.82 -> 9.80-10.2 (tiles 4 x 8: 10.5; compiled for three waves: 9.99),
+//   m=33: 12.1 -> 13.4;  float64 m=17: 3.94 -> 5.84, m=20: 6.08 -> 7.76.
+#ifndef SQFA_CONFIGS2D_F32
+#define SQFA_CONFIGS2D_F32(X) \
+  X(float, 40, 8, 5, 4, 1, 16)
+#endif
+#ifndef SQFA_CONFIGS2D_F64
+#define SQFA_CONFIGS2D_F64(X) \
+  X(double, 24, 8, 3, 4, 1, 16)  \
+  X(double, 32, 16, 2, 8, 1, 32) \
+  X(double, 33, 16, 3, 8, 1, 32) \
+  X(double, 48, 16, 3, 4, 1, 32)
+#endif

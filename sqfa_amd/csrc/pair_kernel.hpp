@@ -335,6 +335,14 @@ __device__ __forceinline__ T dot_cols(const T (&a)[MR], const T (&b)[MR]) {
   }
 }
 
+// 2-D lane layouts (pair_kernel_2d.hpp): the rows of a column are split over the two lanes (lane, lane ^ RS), RS = 16 or
+// 32; an inner product is then the sum of the two lanes' partial sums (one row swap + one add, identical in both lanes:
+// a + b and b + a are the same float).  RS = 0: whole columns per lane, nothing to add.
+template <int RS, typename T> __device__ __forceinline__ T row_total(T v) {
+  if constexpr (RS == 0) return v;
+  else return row_swap_sum<RS>(v, v);
+}
+
 // Sizes m = G (CPL-1) + 1 (SQFA's K+1: 17 = 4*4+1, 33 = 8*4+1) leave ONE real column in the last slot of
 // one lane of the group.  Carried through the tournament it doubles the rounds of every partner
 // (pow2ceil(CPL) = 8 instead of 4) for steps in which a single lane pair of the group does useful work.
@@ -362,7 +370,7 @@ template <int CPL, bool LONE_LAST> constexpr int tournament_slots() { return (LO
 // rotated afterwards against the partner's ALREADY ROTATED slot c, with the algebraically
 // equivalent form  x' = x/cos - tan y_new, i.e.  x^' = x^ - (k gh Dy_new) y^_new,  Dx' = Dx/u,
 // so only one MR-long temporary is live at a time.
-template <typename T, int MR, int CPL, int S, int SWZ, bool LONE_LAST>
+template <typename T, int MR, int CPL, int S, int SWZ, bool LONE_LAST, int RS = 0>
 __device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], int s, T tol2, bool& big) {
   using R = Real<T>;
   constexpr int CE = tournament_slots<CPL, LONE_LAST>();
@@ -381,7 +389,7 @@ __device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
       T rv[MR];
 #pragma unroll
       for (int r = 0; r < MR; ++r) rv[r] = lane_xor_row<S, SWZ>(x[cp][r], s, r);  // partner's slot cp
-      const T gh = dot_cols<T, MR>(x[c], rv);
+      const T gh = row_total<RS>(dot_cols<T, MR>(x[c], rv));
       const T nr1 = lane_xor<S>(nrm[cp], s);
       const T Dp = lane_xor<S>(D[cp], s);
       T u1, ru1, k1, g21;
@@ -426,7 +434,7 @@ __device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
 #ifndef SQFA_PARAM_PRIO
 #define SQFA_PARAM_PRIO 1
 #endif
-template <typename T, int MR, int CPL, int S, int SWZ, bool LONE_LAST, int C0, int C1, int T_>
+template <typename T, int MR, int CPL, int S, int SWZ, bool LONE_LAST, int C0, int C1, int T_, int RS = 0>
 __device__ __forceinline__ void cross_step2(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], int s, T tol2, T tie, bool& big) {
   using R = Real<T>;
   constexpr int NS = (C1 >= 0) ? 2 : 1;
@@ -458,7 +466,7 @@ __device__ __forceinline__ void cross_step2(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
     // step, also runs at raised priority (-1.4 %; +1 % at m=17, no change at m=32: off there)
     constexpr bool PARAM_PRIO = SQFA_PARAM_PRIO != 0 && MR == 16 && CPL == 4 && sizeof(T) == 4;
     if (PARAM_PRIO) __builtin_amdgcn_s_setprio(SQFA_PARAM_PRIO);
-    const T gh = dot_cols<T, MR>(x[c], rv[q]);
+    const T gh = row_total<RS>(dot_cols<T, MR>(x[c], rv[q]));
     T u1, k1, g21;
     rot_scaled(nrm[c], nr1[q], gh, D[c], Dp[q], tol2, tie, u1, ru1[q], k1, g21, big);
     kgh[q] = k1 * gh;
@@ -500,7 +508,7 @@ __device__ __forceinline__ void cross_step2(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
 }
 
 // steps of round t: the slots c < (c ^ t) < CPL (t != 0) or all c (t == 0), two at a time
-template <typename T, int MR, int CPL, int S, int SWZ, bool LONE_LAST, int T_, int CSTART>
+template <typename T, int MR, int CPL, int S, int SWZ, bool LONE_LAST, int T_, int CSTART, int RS = 0>
 __device__ __forceinline__ void cross_t_steps(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], int s, T tol2, T tie, bool& big) {
   // find the next two valid first slots from CSTART on (compile time)
   constexpr auto valid = [](int c) constexpr {
@@ -514,22 +522,22 @@ __device__ __forceinline__ void cross_t_steps(T (&x)[CPL][MR], T (&nrm)[CPL], T 
   if constexpr (first < CPL) {
     constexpr int second = [&]() constexpr { int c = first + 1; while (c < CPL && !valid(c)) ++c; return c; }();
     if constexpr (second < CPL) {
-      cross_step2<T, MR, CPL, S, SWZ, LONE_LAST, first, second, T_>(x, nrm, D, s, tol2, tie, big);
-      cross_t_steps<T, MR, CPL, S, SWZ, LONE_LAST, T_, second + 1>(x, nrm, D, s, tol2, tie, big);
+      cross_step2<T, MR, CPL, S, SWZ, LONE_LAST, first, second, T_, RS>(x, nrm, D, s, tol2, tie, big);
+      cross_t_steps<T, MR, CPL, S, SWZ, LONE_LAST, T_, second + 1, RS>(x, nrm, D, s, tol2, tie, big);
     } else {
-      cross_step2<T, MR, CPL, S, SWZ, LONE_LAST, first, -1, T_>(x, nrm, D, s, tol2, tie, big);
+      cross_step2<T, MR, CPL, S, SWZ, LONE_LAST, first, -1, T_, RS>(x, nrm, D, s, tol2, tie, big);
     }
   }
 }
 
-template <typename T, int MR, int CPL, int S, int SWZ, bool LONE_LAST, int T_ = 0>
+template <typename T, int MR, int CPL, int S, int SWZ, bool LONE_LAST, int T_ = 0, int RS = 0>
 __device__ __forceinline__ void cross_round_paired(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], int s, T tol2, bool& big) {
   constexpr int TP2 = pow2ceil(tournament_slots<CPL, LONE_LAST>());
   if constexpr (T_ < TP2) {
     const int lane_id = (int)(threadIdx.x & 63);
     const T tie = ((lane_id ^ s) > lane_id) ? T(1) : T(-1);
-    cross_t_steps<T, MR, CPL, S, SWZ, LONE_LAST, T_, 0>(x, nrm, D, s, tol2, tie, big);
-    cross_round_paired<T, MR, CPL, S, SWZ, LONE_LAST, T_ + 1>(x, nrm, D, s, tol2, big);
+    cross_t_steps<T, MR, CPL, S, SWZ, LONE_LAST, T_, 0, RS>(x, nrm, D, s, tol2, tie, big);
+    cross_round_paired<T, MR, CPL, S, SWZ, LONE_LAST, T_ + 1, RS>(x, nrm, D, s, tol2, big);
   }
 }
 
@@ -551,14 +559,17 @@ template <typename T, int G, int MR> constexpr bool paired_steps() {
   return (G == 4 && MR >= 16) || G == 8 || (SQFA_PAIRED_G16 && G == 16);
 }
 
-template <typename T, int MR, int G, int CPL, int S>
+// LONE: -1 = derived from the sizes (whole columns per lane: MR is the matrix size); 0 / 1 = given (2-D layouts: MR is the
+// number of rows a lane holds)
+template <typename T, int MR, int G, int CPL, int S, int LONE = -1, int RS = 0>
 __device__ __forceinline__ void cross_rounds_static(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], T tol2, bool& big) {
   if constexpr (S < G) {
+    constexpr bool LONE_LAST = LONE < 0 ? (MR == G * (CPL - 1) + 1) : (LONE != 0);
     if constexpr (paired_steps<T, G, MR>())
-      cross_round_paired<T, MR, CPL, S, swizzled_rows_of_8<T, G, MR>(), (MR == G * (CPL - 1) + 1)>(x, nrm, D, S, tol2, big);
+      cross_round_paired<T, MR, CPL, S, swizzled_rows_of_8<T, G, MR>(), LONE_LAST, 0, RS>(x, nrm, D, S, tol2, big);
     else
-      cross_round<T, MR, CPL, S, swizzled_rows_of_8<T, G, MR>(), (MR == G * (CPL - 1) + 1)>(x, nrm, D, S, tol2, big);
-    cross_rounds_static<T, MR, G, CPL, S + 1>(x, nrm, D, tol2, big);
+      cross_round<T, MR, CPL, S, swizzled_rows_of_8<T, G, MR>(), LONE_LAST, RS>(x, nrm, D, S, tol2, big);
+    cross_rounds_static<T, MR, G, CPL, S + 1, LONE, RS>(x, nrm, D, tol2, big);
   }
 }
 
@@ -569,7 +580,7 @@ __device__ __forceinline__ void cross_rounds_static(T (&x)[CPL][MR], T (&nrm)[CP
 #ifndef SQFA_LOCAL_TOURNAMENT
 #define SQFA_LOCAL_TOURNAMENT 1
 #endif
-template <typename T, int MR, int CPL, int A0, int B0, int A1, int B1>
+template <typename T, int MR, int CPL, int A0, int B0, int A1, int B1, int RS = 0>
 __device__ __forceinline__ void local_step2(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], T tol2, bool& big) {
   using R = Real<T>;
   constexpr int NS = A1 >= 0 ? 2 : 1;
@@ -584,6 +595,10 @@ __device__ __forceinline__ void local_step2(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
 #pragma unroll
       for (int q = 0; q < NS; ++q) gh[q] = R::fma_(x[ca[q]][r], x[cb[q]][r], gh[q]);
     }
+  }
+  if constexpr (RS != 0) {
+#pragma unroll
+    for (int q = 0; q < NS; ++q) gh[q] = row_total<RS>(gh[q]);
   }
   T a1[2], a2[2];
 #pragma unroll
@@ -622,11 +637,11 @@ __device__ __forceinline__ void local_t_steps(T (&x)[CPL][MR], T (&nrm)[CPL], T 
     }
   }
 }
-template <typename T, int MR, int CPL, int C>
+template <typename T, int MR, int CPL, int C, int RS = 0>
 __device__ __forceinline__ void z_visit_steps(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], T tol2, bool& big) {
   if constexpr (C < CPL - 1) {
-    local_step2<T, MR, CPL, C, CPL - 1, -1, -1>(x, nrm, D, tol2, big);
-    z_visit_steps<T, MR, CPL, C + 1>(x, nrm, D, tol2, big);
+    local_step2<T, MR, CPL, C, CPL - 1, -1, -1, RS>(x, nrm, D, tol2, big);
+    z_visit_steps<T, MR, CPL, C + 1, RS>(x, nrm, D, tol2, big);
   }
 }
 template <typename T, int MR, int CPL, int T_>
@@ -640,18 +655,18 @@ __device__ __forceinline__ void local_rounds(T (&x)[CPL][MR], T (&nrm)[CPL], T (
 // The travelling lone column (see SQFA_Z_VISITS above): visit V rotates the last slot against the other
 // slots of the lane, then every lane takes its partner's last slot.  The moves follow the reflected Gray
 // code (xor 1, 2, 1, 4, 1, 2, 1, ...), the last one (xor G/2) brings the column home.
-template <typename T, int MR, int G, int CPL, int SWZ, int V>
+template <typename T, int MR, int G, int CPL, int SWZ, int V, int RS = 0>
 __device__ __forceinline__ void z_visits(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], T tol2, bool& big) {
   if constexpr (V < G) {
     constexpr int Z = CPL - 1;
-    z_visit_steps<T, MR, CPL, 0>(x, nrm, D, tol2, big);
+    z_visit_steps<T, MR, CPL, 0, RS>(x, nrm, D, tol2, big);
     constexpr int NXT = V + 1;
     constexpr int BIT = (NXT == G) ? G / 2 : (NXT & -NXT);
 #pragma unroll
     for (int r = 0; r < MR; ++r) x[Z][r] = lane_xor_row<BIT, SWZ>(x[Z][r], BIT, r);
     nrm[Z] = lane_xor<BIT>(nrm[Z], BIT);
     D[Z] = lane_xor<BIT>(D[Z], BIT);
-    z_visits<T, MR, G, CPL, SWZ, V + 1>(x, nrm, D, tol2, big);
+    z_visits<T, MR, G, CPL, SWZ, V + 1, RS>(x, nrm, D, tol2, big);
   }
 }
 

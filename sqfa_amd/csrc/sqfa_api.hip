@@ -20,25 +20,47 @@ namespace sqfa {
 SQFA_CONFIGS_F32(SQFA_DECL_F32)
 SQFA_CONFIGS_F64(SQFA_DECL_F64)
 
+#define SQFA_DECL2D_F32(T, MR, GC, CPL, TJ, WV, RS) hipError_t launch_pair2d_f32_##MR(const PairParams&, hipStream_t);
+#define SQFA_DECL2D_F64(T, MR, GC, CPL, TJ, WV, RS) hipError_t launch_pair2d_f64_##MR(const PairParams&, hipStream_t);
+SQFA_CONFIGS2D_F32(SQFA_DECL2D_F32)
+SQFA_CONFIGS2D_F64(SQFA_DECL2D_F64)
+
 struct Geometry {
   int MR, G, CPL, TJ, TI, WV;  // TJ: widest tile (B classes); a launch may use TJ/2, TJ/4 ... >= WV
   hipError_t (*launch)(const PairParams&, hipStream_t);
 };
 
+// The geometry table: every whole-column row (pair_kernel.hpp) and every 2-D row (pair_kernel_2d.hpp: GC column lanes x 2
+// row lanes per pair, G = 2 GC lanes per pair) of configs.hpp; a problem of size m runs on the smallest MR >= m.
 static bool find_geometry(int m, int dtype, Geometry* out) {
-#define SQFA_ROW_F32(T, MR_, G_, CPL_, TJ_, WV_) \
-  if (dtype == SQFA_F32 && m <= MR_) { *out = Geometry{MR_, G_, CPL_, TJ_, 64 / G_, WV_, launch_pair_f32_##MR_}; return true; }
-#define SQFA_ROW_F64(T, MR_, G_, CPL_, TJ_, WV_) \
-  if (dtype == SQFA_F64 && m <= MR_) { *out = Geometry{MR_, G_, CPL_, TJ_, 64 / G_, WV_, launch_pair_f64_##MR_}; return true; }
+  bool found = false;
+  Geometry best{};
+  auto consider = [&](int dt, const Geometry& g) {
+    if (dt == dtype && m <= g.MR && (!found || g.MR < best.MR)) {
+      best = g;
+      found = true;
+    }
+  };
+#define SQFA_ROW_F32(T, MR_, G_, CPL_, TJ_, WV_) consider(SQFA_F32, Geometry{MR_, G_, CPL_, TJ_, 64 / G_, WV_, launch_pair_f32_##MR_});
+#define SQFA_ROW_F64(T, MR_, G_, CPL_, TJ_, WV_) consider(SQFA_F64, Geometry{MR_, G_, CPL_, TJ_, 64 / G_, WV_, launch_pair_f64_##MR_});
+#define SQFA_ROW2D_F32(T, MR_, GC_, CPL_, TJ_, WV_, RS_) \
+  consider(SQFA_F32, Geometry{MR_, 2 * GC_, CPL_, TJ_, 64 / (2 * GC_), WV_, launch_pair2d_f32_##MR_});
+#define SQFA_ROW2D_F64(T, MR_, GC_, CPL_, TJ_, WV_, RS_) \
+  consider(SQFA_F64, Geometry{MR_, 2 * GC_, CPL_, TJ_, 64 / (2 * GC_), WV_, launch_pair2d_f64_##MR_});
   SQFA_CONFIGS_F32(SQFA_ROW_F32)
   SQFA_CONFIGS_F64(SQFA_ROW_F64)
-  return false;
+  SQFA_CONFIGS2D_F32(SQFA_ROW2D_F32)
+  SQFA_CONFIGS2D_F64(SQFA_ROW2D_F64)
+  if (found) *out = best;
+  return found;
 }
 
 static int max_dim() {
   int mx = 0;
 #define SQFA_MAX(T, MR_, G_, CPL_, TJ_, WV_) if (MR_ > mx) mx = MR_;
+#define SQFA_MAX2D(T, MR_, GC_, CPL_, TJ_, WV_, RS_) if (MR_ > mx) mx = MR_;
   SQFA_CONFIGS_F32(SQFA_MAX)
+  SQFA_CONFIGS2D_F32(SQFA_MAX2D)
   return mx;
 }
 
