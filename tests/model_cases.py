@@ -136,7 +136,7 @@ def check_orthogonal_fit(model_name, device, tol_loss=1e-6, tol_filters=1e-5):
     assert np.abs((F @ F.T).numpy() - np.eye(3)).max() < 1e-10
 
 
-def check_early_epochs(golden, n_classes, n_dim, n_filters, epochs, device, tol_filters=1e-5):
+def check_early_epochs(golden, n_classes, n_dim, n_filters, epochs, device, tol_filters=1e-5, **fit_kwargs):
     """north_star "learned filters vs the reference to 1e-5", asserted where it is a property of the algorithm: the
     reference's float64 fit stopped after `epochs` epochs (src/sqfa/_optim.py:105-134, `max_epochs`), before its
     fixed-step trajectory amplifies rounding (goldens G6c: BASELINE config 1 shape, G7e: config 5 shape;
@@ -152,7 +152,7 @@ def check_early_epochs(golden, n_classes, n_dim, n_filters, epochs, device, tol_
     assert rel_err(model.filters.detach().cpu(), init.cpu()) < 1e-8      # fit_pca itself
     with torch.no_grad():
         model.parametrizations.filters.original.copy_(init)
-    loss, _ = model.fit(data_statistics=stats, max_epochs=epochs, show_progress=False, return_loss=True)
+    loss, _ = model.fit(data_statistics=stats, max_epochs=epochs, show_progress=False, return_loss=True, **fit_kwargs)
     ref_loss, ref_f = G[f"sqfa_e{epochs}_loss"], G[f"sqfa_e{epochs}_filters"]
     err = rel_err(model.filters.detach().cpu(), ref_f)
     own = rel_err(G[f"sqfa_e{epochs}_cholroute_filters"], ref_f)

@@ -243,6 +243,16 @@ def test_early_epoch_filters_match_reference_f64(golden, C, D, K, epochs):
     mc.check_early_epochs(golden, C, D, K, epochs, DEV, tol_filters=1e-5)
 
 
+@pytest.mark.parametrize("epochs", [1, 2])
+def test_c5_strong_wolfe_early_epochs_f64(epochs):
+    """LBFGS keyword arguments are forwarded (reference src/sqfa/_optim.py:78-82): BASELINE config 5 with
+    line_search_fn="strong_wolfe", the reference's learned filters after 1 and 2 epochs (golden G7f; with the line search
+    the reference agrees with its own Cholesky-route run to 9e-14 there) to 1e-5.  (The FULL strong-Wolfe fit of this
+    configuration is ~11 000 closures, ~8 CPU-hours per reference run: test_c5_config_strong_wolfe_fit_f64 stays skipped.)"""
+    mc.check_early_epochs("g7f_fit_c5_wolfe_early.npz", 100, 3072, 16, epochs, DEV, tol_filters=1e-5,
+                          line_search_fn="strong_wolfe")
+
+
 def _c5_full_fit():
     """One float64 fit of the c5 shape from the golden's exact initial filters, shared by the two tests below."""
     from conftest import load_golden
