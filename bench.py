@@ -163,17 +163,8 @@ def closure_benchmark(C, D, K, model_name, device, steps, lib, with_fit=False):
         evals[0] += 1
         return replay(self)
 
-    from sqfa_amd import _optim
-    staged_run = _optim.ShardedClosure.run
-
-    def counted_run(self, eager=False):
-        if self.state != "on":      # eager warm-up evaluations of the staged closure (replays are counted above)
-            evals[0] += 1
-        return staged_run(self, eager)
-
     model._fused_closure_loss = counted_fused
     torch.cuda.CUDAGraph.replay = counted_replay
-    _optim.ShardedClosure.run = counted_run
     try:
         with contextlib.redirect_stdout(sys.stderr):
             model.fit_pca(data_statistics=stats_for_fit)
@@ -189,7 +180,6 @@ def closure_benchmark(C, D, K, model_name, device, steps, lib, with_fit=False):
     finally:
         torch.cuda.CUDAGraph.replay = replay
         model._fused_closure_loss = fused
-        _optim.ShardedClosure.run = staged_run
     fit = {
         "seconds": fit_seconds, "epochs": int(len(fit_loss)), "closures": evals[0],
         "ms_per_closure": fit_seconds / max(evals[0], 1) * 1e3, "final_loss": float(fit_loss[-1]),

@@ -61,10 +61,6 @@ COMPACT_LBFGS = True
 # fails the loop warns once and continues eagerly -- same arithmetic either way.
 GRAPH_CLOSURE = True
 GRAPH_WARMUP_CLOSURES = 3
-# One GPU, fused closure, sphere / none constraint: run the closure as the stage functions of ShardedClosure (no autograd
-# engine inside the captured graph) instead of capturing FusedClosure's forward + loss.backward().  Same kernels, same
-# results bit for bit; 2-3 fewer tiny launches per replay.
-STAGED_SINGLE_GPU_CLOSURE = True
 
 _NAN_MSG = "Some distances between classes are NaN. Try using float64 or a different regularization parameter."
 _INF_MSG = "Some distances between classes are inf. Try using float64 or a different regularization parameter."
@@ -152,16 +148,10 @@ class ShardedClosure:
     Used by fitting_loop and, directly, by bench.py's N > 1 closure leg."""
 
     @staticmethod
-    def supported(model, prepared, allow_unsharded=False):
-        """allow_unsharded: also accept a model without shards (one GPU): the same stage functions, no collectives,
-        ONE captured graph -- no autograd engine inside the replayed closure (its root-gradient fill and bookkeeping
-        kernels were 2-3 of the ~12 launches of a small closure)."""
+    def supported(model, prepared):
         params = list(model.parameters())
-        shard = getattr(model, "pair_shard", None)
-        is_sharded = (shard is not None and shard.world_size > 1)
-        if not is_sharded and (not allow_unsharded or getattr(model, "class_shard", None) is not None):
-            return False
         return bool(GRAPH_CLOSURE and len(params) == 1 and params[0].is_cuda
+                    and getattr(model, "pair_shard", None) is not None and model.pair_shard.world_size > 1
                     and hasattr(model, "_has_fused_closure") and model._has_fused_closure()
                     and hasattr(model, "_single_node_inputs")
                     and model._single_node_inputs(prepared, allow_class_shard=True) is not None
@@ -179,9 +169,7 @@ class ShardedClosure:
         raw, scatters, means, sphere = model._single_node_inputs(prepared, allow_class_shard=True)
         _, scale, sqrt_mode = distances.fused_spec(model.distance_fun)
         noise = model._noise_scalar()
-        shard = getattr(model, "pair_shard", None)
-        sharded = shard is not None and shard.world_size > 1
-        shard_tuple = shard.shard if sharded else (0, 1)
+        shard = model.pair_shard
         cshard = getattr(model, "class_shard", None)
         C_loc, K = scatters.shape[0], raw.shape[0]
         C = cshard.n_classes if cshard is not None else C_loc
@@ -213,11 +201,10 @@ class ShardedClosure:
                 for r, n in enumerate(cshard.counts):
                     S_full[start:start + n].copy_(recv[r, :n])
                     start += n
-            _native.closure_stage_pairs(S_full, scale, sqrt_mode, weight, shard_tuple, fused)
+            _native.closure_stage_pairs(S_full, scale, sqrt_mode, weight, shard.shard, fused)
 
         def reduce():
-            if sharded:
-                dist.all_reduce(fused, op=dist.ReduceOp.SUM, group=shard.group)
+            dist.all_reduce(fused, op=dist.ReduceOp.SUM, group=shard.group)
 
         def stage_backward():
             gS = fused[3:].view(C, m, m)[offset:offset + C_loc]
@@ -230,13 +217,6 @@ class ShardedClosure:
         def stage_pack():
             box["packed"] = torch.cat([fused[:3], box["grad"].reshape(-1)])
 
-        if not sharded and cshard is None:
-            def whole_closure():            # one GPU: every stage in one go -> one captured graph
-                stage_project()
-                stage_pairs()
-                stage_backward()
-                stage_pack()
-            return [whole_closure], box
         return [stage_project, gather, stage_pairs, reduce, stage_backward, reduce_grad, stage_pack], box
 
     def _capture(self):
@@ -358,9 +338,7 @@ def fitting_loop(model, data_statistics, max_epochs=200, lr=0.1, atol=1e-6, show
         return host[0]
 
     # ---- sharded fits: captured graphs around the collectives (ShardedClosure below) -------------------
-    split = (ShardedClosure(model, prepared)
-             if (len(device_params) == 1 and ShardedClosure.supported(model, prepared, allow_unsharded=STAGED_SINGLE_GPU_CLOSURE))
-             else None)
+    split = ShardedClosure(model, prepared) if (len(device_params) == 1 and ShardedClosure.supported(model, prepared)) else None
 
     def split_closure(defer=False):
         push_parameters()
