@@ -21,6 +21,7 @@
 #include <stdio.h>
 
 #include "../../include/sqfa_hip.h"
+#include "pair_kernel.hpp"   // transposing tree reductions (tree_reduce_blocks), wave_sum
 
 namespace sqfa {
 
@@ -212,6 +213,216 @@ static hipError_t launch_gauss(const GaussParams& p0, hipStream_t stream) {
   return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Register-resident variant (round 3) for small matrices: ONE PAIR PER LANE.  The LDS kernel above walks a 16 x 16
+// factorisation through ~50 dependent LDS round trips with 16 lanes per pair: 4.9 ms for the 10^6 ordered pairs of
+// C=1000, K=16 (forward + backward, float32), two orders of magnitude above its arithmetic.  Here a lane holds the lower
+// triangle of Sbar (M(M+1)/2 registers, M = 4 / 8 / 12 / 16, identity padded), factorises it in place with every loop
+// unrolled (no cross-lane traffic at all), inverts the factor in place (W = R^-1, then Sbar^-1 = W^T W), and the 64
+// pairs of a wave -- same class i, 64 consecutive classes j -- reduce their gradient contributions with the
+// transposing tree reduction of the pair kernel (lane l finishes entries 64 I + l) into a per-wave LDS accumulator.
+// One workgroup (4 waves) per class i walks over all j; the four accumulators are added in wave order at the end:
+// bitwise reproducible, no atomics.  float32 up to m = 16 (136 + ~40 registers), float64 up to m = 8.
+// entry IDX of a lane's gradient contribution, formed on the fly from Sbar^-1 (lower triangle, in `a`) and s (in `d`):
+// IDX < TRI: d/dSigma entry; TRI <= IDX < TRI + M: d/dmu entry
+template <typename T, int M> struct GradEntries {
+  static constexpr int TRI = M * (M + 1) / 2;
+  const T (&a)[TRI];
+  const T (&d)[M];
+  T gq, gl;
+  bool with_inverse;
+  template <int IDX> __device__ __forceinline__ T get() const {
+    if constexpr (IDX < TRI) {
+      constexpr int r = tri_row(IDX), c = IDX - r * (r + 1) / 2;
+      const T outer = gq * d[r] * d[c];
+      return T(0.5) * (with_inverse ? gl * a[IDX] - outer : -outer);
+    } else if constexpr (IDX < TRI + M) {
+      return T(2) * gq * d[IDX - TRI];
+    } else {
+      return T(0);
+    }
+  }
+};
+
+// (two workgroups per CU = 256 VGPRs: without the bound the scheduler batches all 2 x M(M+1)/2 loads of a round ahead of
+// the arithmetic and takes 313 registers at M=16)
+// EXACT: m == M (no identity padding: no selects, rows of M elements, 16-byte row loads when M % 4 == 0 (float32) / M % 2
+// == 0 (float64) and the matrices are 16-byte aligned, which the launcher checks)
+template <typename T, int M, bool EXACT>
+__global__ __launch_bounds__(256, (M * (M + 1) / 2) * (int)(sizeof(T) / 4) <= 40 ? 4 : 2) void gauss_pair_reg_kernel(const GaussParams p) {
+  constexpr int TRI = M * (M + 1) / 2, NACC = TRI + M;
+  __shared__ T s_acc[4][NACC | 1];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = blockIdx.x, m = p.m;
+  const T* muA = static_cast<const T*>(p.muA);
+  const T* covA = static_cast<const T*>(p.covA);
+  const T* muB = static_cast<const T*>(p.muB);
+  const T* covB = static_cast<const T*>(p.covB);
+  const T* gQ = static_cast<const T*>(p.gQ);
+  const T* gLD = static_cast<const T*>(p.gLD);
+  const bool want_grad = p.gcovA != nullptr;
+  if (want_grad) {
+    for (int k = lane; k < NACC; k += 64) s_acc[wave][k] = T(0);   // wave-private: no block barrier needed
+  }
+  const T* ci = covA + (size_t)i * m * m;
+  auto at = [](int r, int c) constexpr { return r * (r + 1) / 2 + c; };  // c <= r
+
+  const int rounds = (p.nB + 255) / 256;
+  for (int it = 0; it < rounds; ++it) {
+    const int j = it * 256 + tid;
+    const bool valid = j < p.nB;
+    const T* cj = covB + (size_t)(valid ? j : 0) * m * m;
+    // Sigma_i is the same in every round: hidden from loop-invariant code motion, or its 136 values would be kept in
+    // registers across the whole loop (321 VGPRs and spills at M=16 instead of ~200)
+    const T* cir = ci;
+    asm volatile("" : "+s"(cir));
+    T a[TRI], d[M];
+    // ---- Sbar = (Sigma_i + Sigma_j)/2 and its Cholesky factor R (lower, in place), ROW BY ROW: row r needs the finished
+    //      rows above it and its own entries only, so the loads of a row sit next to their use (live set: the triangle
+    //      built so far) ----
+    T rdiag[M];
+    T ld = T(0);
+    constexpr int VW = 16 / (int)sizeof(T);
+    struct alignas(16) RowVec { T v[VW]; };
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+      T row[M];
+      if constexpr (EXACT) {
+        d[r] = muA[(size_t)i * M + r] - muB[(size_t)(valid ? j : 0) * M + r];
+        if constexpr (M % VW == 0) {
+#pragma unroll
+          for (int c0 = 0; c0 <= r; c0 += VW) {
+            const RowVec vi = *reinterpret_cast<const RowVec*>(cir + r * M + c0);
+            const RowVec vj = *reinterpret_cast<const RowVec*>(cj + r * M + c0);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) row[(c0 + e < M) ? c0 + e : 0] = T(0.5) * (vi.v[e] + vj.v[e]);
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c <= r; ++c) row[c] = T(0.5) * (cir[r * M + c] + cj[r * M + c]);
+        }
+      } else {
+        const bool rr = r < m;
+        const int rc = rr ? r : m - 1;   // clamped addresses, selected values: no branches
+        const T dv = muA[(size_t)i * m + rc] - muB[(size_t)(valid ? j : 0) * m + rc];
+        d[r] = rr ? dv : T(0);
+#pragma unroll
+        for (int c = 0; c <= r; ++c) {
+          const int cc = c < m ? c : m - 1;
+          const T v = T(0.5) * (cir[rc * m + cc] + cj[rc * m + cc]);
+          row[c] = (rr && c < m) ? v : (r == c ? T(1) : T(0));
+        }
+      }
+      // R[r][c] = (Sbar[r][c] - sum_{k<c} R[r][k] R[c][k]) / R[c][c];  R[r][r] = sqrt(Sbar[r][r] - sum_{k<r} R[r][k]^2)
+#pragma unroll
+      for (int c = 0; c < r; ++c) {
+        T t = row[c];
+#pragma unroll
+        for (int k = 0; k < c; ++k) t -= row[k] * a[at(c, k)];
+        row[c] = t * rdiag[c];
+      }
+      T piv = row[r];
+#pragma unroll
+      for (int k = 0; k < r; ++k) piv -= row[k] * row[k];
+      const T rs = g_rsqrt<T>(piv);   // non-positive pivot -> NaN downstream, never a fault
+      rdiag[r] = rs;
+      const T dk = piv * rs;
+      ld += g_log(dk);
+#pragma unroll
+      for (int c = 0; c < r; ++c) a[at(r, c)] = row[c];
+      a[at(r, r)] = dk;
+    }
+    ld *= T(2);
+    // ---- z = R^-1 delta, Q = |z|^2 ----
+    T q = T(0);
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+      T t = d[k];
+#pragma unroll
+      for (int c = 0; c < k; ++c) t -= a[at(k, c)] * d[c];
+      d[k] = t * rdiag[k];   // d becomes z
+      q += d[k] * d[k];
+    }
+    if (valid) {
+      if (p.Q != nullptr) static_cast<T*>(p.Q)[(size_t)i * p.nB + j] = q;
+      if (p.LD != nullptr) static_cast<T*>(p.LD)[(size_t)i * p.nB + j] = ld;
+    }
+    if (!want_grad) continue;
+    const T gq = (valid && gQ != nullptr) ? gQ[(size_t)i * p.nB + j] : T(0);
+    const T gl = (valid && gLD != nullptr) ? gLD[(size_t)i * p.nB + j] : T(0);
+    // ---- s = R^-T z (in place, from the last row up) ----
+#pragma unroll
+    for (int k = M - 1; k >= 0; --k) {
+      T t = d[k];
+#pragma unroll
+      for (int r = k + 1; r < M; ++r) t -= a[at(r, k)] * d[r];
+      d[k] = t * rdiag[k];   // d becomes s
+    }
+    if (gLD != nullptr) {
+      // ---- W = R^-1 in place, column by column: column c of W needs R[r][k] for k >= c only, so it may overwrite
+      //      column c of R as soon as it is complete ----
+#pragma unroll
+      for (int c = 0; c < M; ++c) {
+        T wc[M];
+        wc[c] = rdiag[c];
+#pragma unroll
+        for (int r = c + 1; r < M; ++r) {
+          T sum = T(0);
+#pragma unroll
+          for (int k = c; k < r; ++k) sum += a[at(r, k)] * wc[k];
+          wc[r] = -sum * rdiag[r];
+        }
+#pragma unroll
+        for (int r = c; r < M; ++r) a[at(r, c)] = wc[r];
+      }
+      // ---- Sbar^-1 = W^T W in place, row by row: row r needs the rows k >= r of W, so it may overwrite row r ----
+#pragma unroll
+      for (int r = 0; r < M; ++r) {
+        T row[M];
+#pragma unroll
+        for (int c = 0; c <= r; ++c) {
+          T inv = T(0);
+#pragma unroll
+          for (int k = r; k < M; ++k) inv += a[at(k, r)] * a[at(k, c)];
+          row[c] = inv;
+        }
+#pragma unroll
+        for (int c = 0; c <= r; ++c) a[at(r, c)] = row[c];
+      }
+    }
+    // ---- 1/2 (gl Sbar^-1 - gq s s^T) and 2 gq s, summed over the 64 pairs of the wave: lane l finishes entries 64 I + l ----
+    {
+      const GradEntries<T, M> prod{a, d, gq, gl, gLD != nullptr};
+      T* acc = s_acc[wave];
+      tree_reduce_blocks<6, 0, (NACC + 63) / 64, NACC, T>(prod, lane, [&](int idx, T v) { acc[idx] += v; });
+    }
+  }
+  if (!want_grad) return;
+  __syncthreads();
+  T* gcov = static_cast<T*>(p.gcovA) + (size_t)i * m * m;
+  for (int e = tid; e < m * m; e += 256) {
+    const int rr = e / m, cc = e % m;
+    const int hi = rr > cc ? rr : cc, lo = rr > cc ? cc : rr;
+    const int idx = hi * (hi + 1) / 2 + lo;
+    gcov[e] = ((s_acc[0][idx] + s_acc[1][idx]) + s_acc[2][idx]) + s_acc[3][idx];
+  }
+  if (p.gmuA != nullptr) {
+    T* gmu = static_cast<T*>(p.gmuA) + (size_t)i * m;
+    for (int e = tid; e < m; e += 256)
+      gmu[e] = ((s_acc[0][TRI + e] + s_acc[1][TRI + e]) + s_acc[2][TRI + e]) + s_acc[3][TRI + e];
+  }
+}
+
+template <typename T, int M>
+static hipError_t launch_gauss_reg(const GaussParams& p, hipStream_t stream) {
+  const bool aligned = (reinterpret_cast<size_t>(p.covA) % 16) == 0 && (reinterpret_cast<size_t>(p.covB) % 16) == 0;
+  if (p.m == M && aligned)
+    hipLaunchKernelGGL((gauss_pair_reg_kernel<T, M, true>), dim3(p.nA), dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL((gauss_pair_reg_kernel<T, M, false>), dim3(p.nA), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
 }  // namespace sqfa
 
 using namespace sqfa;
@@ -228,6 +439,22 @@ extern "C" int sqfa_gauss_pair_terms(const void* muA, const void* covA, int nA, 
   if (gcovA_out != nullptr && gQ == nullptr && gLD == nullptr) return SQFA_ERR_BAD_ARGUMENT;
   GaussParams p{muA, covA, muB, covB, gQ, gLD, Q_out, LD_out, gmuA_out, gcovA_out, nA, nB, m, 1};
   hipError_t e;
+#ifndef SQFA_GAUSS_REG
+#define SQFA_GAUSS_REG 1   // 0: always the LDS kernel (development A/B)
+#endif
+  // small matrices: one pair per lane, everything in registers (float32 up to 16, float64 up to 8)
+  if (SQFA_GAUSS_REG && dtype == SQFA_F32 && m <= 16) {
+    if (m <= 4) e = launch_gauss_reg<float, 4>(p, stream);
+    else if (m <= 8) e = launch_gauss_reg<float, 8>(p, stream);
+    else if (m <= 12) e = launch_gauss_reg<float, 12>(p, stream);
+    else e = launch_gauss_reg<float, 16>(p, stream);
+    return e == hipSuccess ? SQFA_OK : SQFA_ERR_LAUNCH;
+  }
+  if (SQFA_GAUSS_REG && dtype == SQFA_F64 && m <= 8) {   // (float64 m=12: 156 registers of triangle, 219 spilled: LDS kernel)
+    if (m <= 4) e = launch_gauss_reg<double, 4>(p, stream);
+    else e = launch_gauss_reg<double, 8>(p, stream);
+    return e == hipSuccess ? SQFA_OK : SQFA_ERR_LAUNCH;
+  }
 #define SQFA_GAUSS_DISPATCH(T)                                         \
   if (m <= 4) e = launch_gauss<T, 4>(p, stream);                       \
   else if (m <= 8) e = launch_gauss<T, 8>(p, stream);                  \

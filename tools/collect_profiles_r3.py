@@ -13,7 +13,7 @@ for w in ("c3", "c2", "c3-sqfa", "c4", "c5"):
     if stats:
         shutil.copy(stats[0], os.path.join(OUT, f"r3_{w}_kernel_stats.csv"))
 for name in ("all_sizes", "shard_timings", "fit_benchmark", "gauss_pairs", "overlap_probe", "projection_kernel",
-             "projection_dims", "clock_probe", "scale_probe"):
+             "projection_dims", "clock_probe", "scale_probe", "gauss_sizes"):
     src = os.path.join(P, name + ".txt")
     if os.path.exists(src):
         txt = "\n".join(l for l in open(src).read().splitlines() if "amdgpu.ids" not in l)

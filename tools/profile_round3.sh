@@ -32,6 +32,7 @@ python3 tools/all_sizes.py > $P/all_sizes.txt 2>&1
 python3 tools/time_shard.py > $P/shard_timings.txt 2>&1
 python3 tools/fit_benchmark.py c1 c2 c2s c5 c3 > $P/fit_benchmark.txt 2>&1
 python3 tools/time_gauss_pairs.py > $P/gauss_pairs.txt 2>&1
+python3 tools/time_gauss_sizes.py > $P/gauss_sizes.txt 2>&1
 python3 tools/overlap_probe.py c3 > $P/overlap_probe.txt 2>&1
 python3 tools/overlap_probe.py c4 >> $P/overlap_probe.txt 2>&1
 python3 tools/time_projection_kernel.py > $P/projection_kernel.txt 2>&1
