@@ -80,6 +80,22 @@ def make_feature_scatters(C, D, K, model, device, dtype=torch.float32, seed=1234
     return S.to(dtype).contiguous(), scale
 
 
+def capture_closure(closure, params):
+    """(replay, captured): `closure` (forward + backward into params' .grad) captured once in a HIP graph; if the capture
+    fails the eager closure itself is returned and `captured` is False."""
+    for p in params:
+        p.grad = None
+    try:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            closure()
+        return g.replay, True
+    except Exception as err:
+        sys.stderr.write(f"bench.py: HIP graph capture of the closure failed ({err}); timing eager closures\n")
+        torch.cuda.synchronize()
+        return closure, False
+
+
 def closure_benchmark(C, D, K, model_name, device, steps, lib, with_fit=False):
     """Secondary measurement (metric M2 of SURVEY.md 8d, N=1 only): one full closure = projection
     of the (C,D,D) scatters through the current filters (streaming HIP kernel), fused pairwise
@@ -114,12 +130,20 @@ def closure_benchmark(C, D, K, model_name, device, steps, lib, with_fit=False):
     for _ in range(max(3, min(25, steps))):   # the statistics were just generated on an idle GPU: reach the sustained clock
         closure()
     torch.cuda.synchronize()
+    # the timed closures are replayed from a captured HIP graph -- what fit() does after three eager closures
+    # (sqfa_amd/_optim.py) -- so that the number is the GPU's, not the box's host (eager: ~10 launches + the autograd
+    # engine per closure; the c2-sized closure read 0.20-0.32 ms depending on the box)
+    replay, graphed = capture_closure(closure, [model.parametrizations.filters.original])
+    for _ in range(3):
+        replay()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):                    # timed region: no profiling events
-        loss = closure()
+        replay()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    lib.sqfa_airm_profile(1)                  # separate short pass with HIP events around the kernels
+    loss = closure()
+    lib.sqfa_airm_profile(1)                  # separate short pass with HIP events around the kernels (plain launches)
     for _ in range(max(5, min(30, steps))):
         closure()
     torch.cuda.synchronize()
@@ -137,6 +161,7 @@ def closure_benchmark(C, D, K, model_name, device, steps, lib, with_fit=False):
         "unit": "closures/s",
         "ms_per_closure": elapsed / steps * 1e3,
         "what": f"projection F Psi_c F^T of (C={C},D={D},D) scatters + fused pairwise loss+grad + backward to the raw filters ({model_name}, K={K})",
+        "replayed_from_hip_graph": graphed,
         "pair_kernel_ms": ms2.value / max(n2.value, 1),
         "loss": loss.item(),
         "roofline": {
@@ -248,12 +273,21 @@ def c4_closure_leg(world, rank, device, pair_shard, steps, lib, fence, dist):
     for _ in range(6):          # three eager evaluations, the capture, two replays
         packed = closure()
     fence()
+    timed, graphed_single = closure, False
+    if world == 1:              # one GPU: replay the closure from a captured graph as fit() does (N > 1: ShardedClosure does)
+        replay, graphed_single = capture_closure(closure, [model.parametrizations.filters.original])
+        if graphed_single:
+            timed = replay
+        for _ in range(2):
+            timed()
+        fence()
     gen_seconds = time.perf_counter() - t_gen
     t0 = time.perf_counter()
     for _ in range(steps):
-        packed = closure()
+        timed()
     fence()
     seconds = time.perf_counter() - t0
+    packed = closure() if world == 1 else packed
     lib.sqfa_airm_profile(1)    # separate profiled pass (HIP events around project_kernel / pair_tile_kernel),
     for _ in range(max(3, min(10, steps))):   # as plain launches: a graph replay does not repeat the event records
         closure(True)
@@ -279,7 +313,7 @@ def c4_closure_leg(world, rank, device, pair_shard, steps, lib, fence, dist):
         "value": steps / seconds, "unit": "closures/s", "n_gpus": world, "steps": steps, "warmup": 6,
         "ms_per_closure": seconds / steps * 1e3, "scaling": "strong", "loss": loss,
         "collectives_per_closure": 3 if world > 1 else 0,
-        "graphs_per_closure": 4 if (world > 1 and sharded.state == "on") else 0,
+        "graphs_per_closure": (4 if sharded.state == "on" else 0) if world > 1 else (1 if graphed_single else 0),
         "pair_kernel_ms": pair_ms,
         "projection": {"bound": "hbm", "kernel": "project_kernel", "kernel_ms": proj_ms, "achieved": gbs, "peak": HBM_PEAK_GBS,
                        "unit": "GB/s per rank", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": byts},

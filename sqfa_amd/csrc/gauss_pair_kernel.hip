@@ -250,7 +250,8 @@ template <typename T, int M> struct GradEntries {
 // EXACT: m == M (no identity padding: no selects, rows of M elements, 16-byte row loads when M % 4 == 0 (float32) / M % 2
 // == 0 (float64) and the matrices are 16-byte aligned, which the launcher checks)
 template <typename T, int M, bool EXACT>
-__global__ __launch_bounds__(256, (M * (M + 1) / 2) * (int)(sizeof(T) / 4) <= 40 ? 4 : 2) void gauss_pair_reg_kernel(const GaussParams p) {
+__global__ __launch_bounds__(256, (M * (M + 1) / 2) * (int)(sizeof(T) / 4) <= 40 ? 4 : ((M * (M + 1) / 2) * (int)(sizeof(T) / 4) <= 140 ? 2 : 1))
+void gauss_pair_reg_kernel(const GaussParams p) {
   constexpr int TRI = M * (M + 1) / 2, NACC = TRI + M;
   __shared__ T s_acc[4][NACC | 1];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -442,6 +443,9 @@ extern "C" int sqfa_gauss_pair_terms(const void* muA, const void* covA, int nA, 
 #ifndef SQFA_GAUSS_REG
 #define SQFA_GAUSS_REG 1   // 0: always the LDS kernel (development A/B)
 #endif
+#ifndef SQFA_GAUSS_REG_F64_MAX
+#define SQFA_GAUSS_REG_F64_MAX 16   // float64 m > 8: the triangle needs 156 / 272 registers -- one wave per SIMD, part of it in AGPRs
+#endif
   // small matrices: one pair per lane, everything in registers (float32 up to 16, float64 up to 8)
   if (SQFA_GAUSS_REG && dtype == SQFA_F32 && m <= 16) {
     if (m <= 4) e = launch_gauss_reg<float, 4>(p, stream);
@@ -450,9 +454,11 @@ extern "C" int sqfa_gauss_pair_terms(const void* muA, const void* covA, int nA, 
     else e = launch_gauss_reg<float, 16>(p, stream);
     return e == hipSuccess ? SQFA_OK : SQFA_ERR_LAUNCH;
   }
-  if (SQFA_GAUSS_REG && dtype == SQFA_F64 && m <= 8) {   // (float64 m=12: 156 registers of triangle, 219 spilled: LDS kernel)
+  if (SQFA_GAUSS_REG && dtype == SQFA_F64 && m <= SQFA_GAUSS_REG_F64_MAX) {
     if (m <= 4) e = launch_gauss_reg<double, 4>(p, stream);
-    else e = launch_gauss_reg<double, 8>(p, stream);
+    else if (m <= 8) e = launch_gauss_reg<double, 8>(p, stream);
+    else if (m <= 12) e = launch_gauss_reg<double, 12>(p, stream);
+    else e = launch_gauss_reg<double, 16>(p, stream);
     return e == hipSuccess ? SQFA_OK : SQFA_ERR_LAUNCH;
   }
 #define SQFA_GAUSS_DISPATCH(T)                                         \
