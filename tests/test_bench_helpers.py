@@ -68,3 +68,31 @@ def test_bench_launcher_stops_the_job_when_a_rank_dies():
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and "rank 1 exited with code 7" in out.stderr
     assert time.time() - t0 < 45          # did not sit out the other rank's wait
+
+
+def test_class_shard_generator_is_the_same_data_set_for_every_rank_count():
+    """bench.py's c4 closure leg: every rank generates only its own class shard; the union over the ranks must be the
+    data set a single rank generates (one generator seed per chunk of 50 classes), for even and uneven splits."""
+    C, D = 130, 24
+    whole = bench.make_class_shard_statistics(C, D, 0, C, torch.device("cpu"))
+    assert whole.shape == (C, D, D) and torch.allclose(whole, whole.transpose(1, 2))
+    for world in (2, 3, 8):
+        parts = [bench.make_class_shard_statistics(C, D, r * C // world, (r + 1) * C // world, torch.device("cpu"))
+                 for r in range(world)]
+        assert torch.equal(torch.cat(parts), whole)
+    # second moments: Sigma + mu mu^T with Sigma = A A^T + 0.05 I  ->  positive definite
+    assert torch.linalg.eigvalsh(whole.double()).min() > 0.04
+
+
+def test_replicas_agree_on_one_rank():
+    """parallel.replicas_agree compares an exact checksum of the bit patterns; on one gloo rank it must hold trivially
+    and must be sensitive to a one-ulp change (the two-rank behaviour is tested in tests/test_distributed_gloo.py)."""
+    import torch.distributed as dist
+    from sqfa_amd.parallel import replicas_agree
+    port = 34500 + os.getpid() % 2000
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        a = torch.randn(7, 5)
+        assert replicas_agree([a, a.double()])
+    finally:
+        dist.destroy_process_group()
