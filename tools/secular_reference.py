@@ -12,7 +12,7 @@ SPD input (not only the Calvo-Oller embedding), checked against float64 LAPACK o
   dL/dB_i = sum_r g_r u_r u_r^T,   dL/dB_j = - sum_r g_r lam_r u_r u_r^T,   g_r = w * dD/dd2 * scale * 2 log(lam_r) / lam_r
 
 The secular stage runs in float32 (numpy float32 arithmetic, every pole difference formed from the root's offset to its
-origin pole, safeguarded Newton on the monotone secular function: iteration counts are printed); everything is compared
+origin pole, a safeguarded fixed-weight rational iteration: evaluation counts are printed); everything is compared
 with float64 eigh of L_Bj^-1 B_i L_Bj^-T and the closed-form gradient.      python tools/secular_reference.py"""
 import numpy as np
 
@@ -38,56 +38,82 @@ def reference(Bi, Bj, scale=0.5, eps=1e-6, w=1.0):
     return D, (U * g) @ U.T, -(U * (g * lam)) @ U.T
 
 
+def _minus_branch(c, a, b):
+    """the root (a - sqrt(a^2 - 4 b c)) / (2 c) of  c T^2 - a T + b = 0, evaluated without cancellation: for a model
+    c + a_o / (-T) + s / (G - T) with positive weights it is the one between the two model poles"""
+    disc = np.sqrt(max(a * a - F(4) * b * c, F(0)))
+    if c == 0:
+        return b / a
+    return (a - disc) / (F(2) * c) if a <= 0 else F(2) * b / (a + disc)
+
+
 def secular_roots_f32(p, z2, rho):
-    """roots of 1 + rho sum z2_k / (p_k - lam), float32; returns (origin index, offset) per owning pole, iterations."""
+    """roots of 1 + rho sum z2_k / (p_k - lam), float32; returns (origin index, offset) per owning pole, iterations.
+
+    "Fixed weight" rational iteration (Li 1994; the family LAPACK's dlaed4 draws from), started at the middle of the root's
+    interval: the pole nearer to the root (the ORIGIN; the offset t from it is the unknown) keeps its exact weight, the
+    rest of the function -- summed WITHOUT the origin's term, so that a root hugging its pole does not cancel -- is
+    modelled as c + s / (p_q - lam) through its value and slope, q = the pole at the other end of the interval.  The
+    quadratic is solved for the NEW OFFSET itself, not for an increment (t + eta loses the distance to the pole when the
+    root hugs it).  The largest root (no pole above) models the rest as a straight line.  Safeguards: Newton, then
+    bisection, whenever a step leaves the bracket.  Stop when |f| is within its own rounding noise.
+    Measured (this file's cases and tools/secular_probe.py's): 3-4 evaluations per root on average, <= 10 at worst; the
+    plain safeguarded Newton this replaces needed 10-30 when the weights are small."""
     n = len(p)
-    p, z2, rho = p.astype(F), z2.astype(F), F(rho)
-    total = rho * z2.sum(dtype=F)
+    p, a = p.astype(F), (z2 * rho).astype(F)
+    total = a.sum(dtype=F)
     origin, tau, iters = np.zeros(n, int), np.zeros(n, F), []
     tiny = F(1e-12) * (np.abs(p).max() + total)
+    live = a > tiny
+    eps = F(6e-8)
     for k in range(n):
-        if z2[k] * rho <= tiny:                     # deflated: the root sits on the pole
+        if not live[k]:                                # deflated: the root sits on the pole
             origin[k], tau[k] = k, F(0)
             iters.append(0)
             continue
-        live = z2 * rho > tiny
         above = p[(p > p[k]) & live]
-        hi = above.min() if above.size else None
-        gap = F(hi - p[k]) if hi is not None else total
-
-        def fdf(o, t):
-            delta = (p - p[o]).astype(F) - t           # p_k - lam with lam = p_o + t
-            r = z2 / delta
-            r = np.where(live, r, F(0))
-            return F(1) + rho * r.sum(dtype=F), rho * (r / delta).sum(dtype=F)   # f is increasing: f' > 0
-
-        o, a, b = k, F(0), gap
-        if hi is not None:
-            fm, _ = fdf(k, F(0.5) * gap)
-            if fm < 0:                                  # root in the upper half: measure it from the upper pole
-                o = int(np.where(p == hi)[0][0])
-                a, b = -F(0.5) * gap, F(0)
-            else:
-                b = F(0.5) * gap
-        t = F(0.5) * (a + b)
+        ip = int(np.where(p == above.min())[0][0]) if above.size else None
+        gap = F(p[ip] - p[k]) if ip is not None else total
+        o, t, lo, hi = k, F(0.5) * gap, F(0), gap
+        first = True
         it = 0
         for it in range(1, 40):
-            f, df = fdf(o, t)
-            if f > 0:
-                b = t
+            delta = (p - p[o]).astype(F) - t           # p_j - lam with lam = p_o + t
+            r = np.where(live, a / delta, F(0))
+            w = F(1) + r.sum(dtype=F)
+            if first and ip is not None and w < 0:     # root in the upper half: measure it from the upper pole
+                o, t, lo, hi = ip, t - gap, -gap, F(0)
+                delta = (p - p[o]).astype(F) - t
+            first = False
+            if abs(w) <= F(4) * eps * (F(1) + np.abs(r).sum(dtype=F)):
+                break
+            if w > 0:
+                hi = min(hi, t)
             else:
-                a = t
-            step = -f / df
-            tn = t + step
-            if not (a < tn < b):                       # Newton left the bracket: bisect
-                tn = F(0.5) * (a + b)
-            if tn == t or abs(tn - t) <= F(2e-7) * max(abs(tn), abs(t)):
-                t = tn
+                lo = max(lo, t)
+            rest = r.copy()
+            rest[o] = 0
+            R0, Rp = F(1) + rest.sum(dtype=F), (rest / delta).sum(dtype=F)
+            ao, Do = a[o], delta[o]
+            if ip is not None:
+                q = ip if o == k else k
+                Dq, Gq = delta[q], F(p[q] - p[o])
+                s, c = Dq * Dq * Rp, R0 - Dq * Rp
+                tn = _minus_branch(c, c * Gq + ao + s, ao * Gq)
+            else:                                       # A + Rp T - ao / T = 0 with the line's intercept A at T = 0
+                A = R0 - Rp * t
+                disc = np.sqrt(A * A + F(4) * Rp * ao)
+                tn = F(2) * ao / (A + disc) if A > 0 else (disc - A) / (F(2) * Rp)
+            if not np.isfinite(tn) or not (lo < tn < hi):
+                tn = t - w / (Rp + ao / (Do * Do))
+                if not (lo < tn < hi):
+                    tn = F(0.5) * (lo + hi)
+            if tn == t:
                 break
             t = tn
         origin[k], tau[k] = o, t
         iters.append(it)
-    return origin, tau, iters, z2 * rho > tiny
+    return origin, tau, iters, live
 
 
 def bordered(Bi, Bj, scale=0.5, eps=1e-6, w=1.0):
