@@ -31,5 +31,8 @@ namespace sqfa {
 hipError_t SQFA_CAT(launch_pair_, SQFA_TAG, SQFA_MR)(const PairParams& p, hipStream_t stream) {
   return launch_pair_tiles<PairCfg<SQFA_T, SQFA_MR, SQFA_G, SQFA_CPL, SQFA_TJ, SQFA_WAVES>>(p, stream);
 }
+hipError_t SQFA_CAT(launch_factor_, SQFA_TAG, SQFA_MR)(const PairParams& p, hipStream_t stream) {
+  return launch_class_factors<PairCfg<SQFA_T, SQFA_MR, SQFA_G, SQFA_CPL, SQFA_TJ, SQFA_WAVES>>(p, stream);
+}
 }  // namespace sqfa
 #endif

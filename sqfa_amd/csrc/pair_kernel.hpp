@@ -108,7 +108,7 @@ template <typename T> struct Real;
 template <> struct Real<float> {
   static constexpr float kEps = 1.1920929e-07f;
 #ifndef SQFA_EARLY2_F32
-#define SQFA_EARLY2_F32 1.0e-7f
+#define SQFA_EARLY2_F32 1.0e-6f
 #endif
   static constexpr float kEarly2 = SQFA_EARLY2_F32;  // a sweep in which every cos^2 between columns stays below this is the last one
 #ifndef SQFA_RENORM_LOG2
@@ -805,6 +805,18 @@ struct PairCfg {
   // L_j^-1 staged in LDS as a packed lower triangle (one-wave workgroups, m >= 32: 8 instead of 7
   // workgroups per CU) or as a full MR x MR block (smaller sizes: no occupancy to gain, and the
   // regular row pitch keeps the back-transform's LDS reads vectorised and out of the spill range)
+  // K0b (class_factor_kernel below): the A-side factor handed to the pair kernel is not the Cholesky factor L_i but
+  // L_i V_i with the columns made orthogonal by a few Jacobi sweeps of their own -- still a factor of Sigma_i, so the
+  // pencil is unchanged, but the pair sweeps start from columns that are orthogonal in the plain inner product and
+  // converge a sweep earlier ("class factors").  0 sweeps: the pass is off and L_i stays triangular.
+#ifndef SQFA_FACTOR_SWEEPS
+#define SQFA_FACTOR_SWEEPS -1  // -1: by size
+#endif
+#ifndef SQFA_FACTOR_MIN_M
+#define SQFA_FACTOR_MIN_M 12
+#endif
+  static constexpr int FACTOR_SWEEPS = SQFA_FACTOR_SWEEPS >= 0 ? SQFA_FACTOR_SWEEPS : (MR_ >= SQFA_FACTOR_MIN_M ? 2 : 0);
+  static constexpr bool DENSE_FACTOR = FACTOR_SWEEPS > 0;
   static constexpr bool PACK_LINV = MR_ >= 32;
   static constexpr int LINV_ELEMS = PACK_LINV ? MR_ * (MR_ + 1) / 2 : MR_ * MR_;
   static_assert(G * CPL >= MR, "not enough column slots");
@@ -941,7 +953,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
           // every lane, so those terms are skipped at compile time (m=32 -1.6 %, m=17 -0.6 %).  Not for the
           // float32 m=16 instantiation: no time to gain there (1.076 vs 1.078 ms) and the shorter live ranges
           // make the register allocator spill 7 VGPRs instead of 1 (+30 MB of scratch traffic per launch)
-          constexpr bool SKIP_ZEROS = !(sizeof(T) == 4 && MR == 16);
+          constexpr bool SKIP_ZEROS = !Cfg::DENSE_FACTOR && !(sizeof(T) == 4 && MR == 16);
           if (!SKIP_ZEROS || k >= c * G) acc[c] = R::fma_(l, x[c][k], acc[c]);
         }
       }
@@ -1208,6 +1220,137 @@ hipError_t launch_pair_tiles(const PairParams& p, hipStream_t stream) {
     hipLaunchKernelGGL((pair_tile_kernel<Cfg, false>), grid, dim3(Cfg::THREADS), 0, stream, p, static_cast<const T*>(p.LT),
                        static_cast<const T*>(p.Linv), static_cast<const T*>(p.W), static_cast<const T*>(p.EW));
   return hipGetLastError();
+}
+
+// ---- K0b: per-class factor pass ------------------------------------------------------------
+// One lane group per CLASS (same column layout as the pair kernel: slot c of lane g is column c*G + g): the columns of
+// L_i are read from LT, orthogonalised by at most `max_sweeps` sweeps of the pair kernel's own rotations, and written back
+// in place.  Any orthogonal V leaves  (L_i V)(L_i V)^T = Sigma_i, so the sweeps need not converge.
+//
+// The arithmetic is DOUBLE whatever the problem's type (SQFA_FACTOR_F64): the factor is shared by every pair of its class,
+// so its rounding errors do not average out over the pairs the way the pair sweeps' own do -- float32 sweeps here
+// tripled the float32 gradient error (2.4e-7 -> 7.3e-7 at m=16, 0.9e-6 -> 1.65e-6 at m=32, against the float64 kernels).
+#ifndef SQFA_FACTOR_F64
+#define SQFA_FACTOR_F64 1
+#endif
+// The pass has its own lane geometry (LT's layout does not depend on it): a launch is a handful of lone waves whose duration is
+// one wave's latency, so a class is spread over MORE lanes than a pair is in the pair kernel (fewer columns per lane =
+// fewer dependent instructions per sweep).
+template <typename Tio_, int MR_>
+struct FactorCfg {
+  using io_type = Tio_;
+  static constexpr int MR = MR_;
+#ifndef SQFA_FACTOR_G
+  // (double state: 16 lanes x 3 slots x 48 rows would need 576 VGPRs -- measured 0.9 ms of spills -- so sizes above 33 take 32 lanes)
+  static constexpr int G = MR_ <= 12 ? 4 : (MR_ <= 24 ? 8 : (MR_ <= 33 ? 16 : 32));
+#else
+  static constexpr int G = SQFA_FACTOR_G;
+#endif
+  static constexpr int CPL = (MR_ + G - 1) / G;
+  static constexpr int PPW = 64 / G;
+};
+
+template <typename Cfg>
+__global__ __launch_bounds__(64) void class_factor_kernel(typename Cfg::io_type* __restrict__ LT, int nA, int max_sweeps) {
+  using Tio = typename Cfg::io_type;
+#if SQFA_FACTOR_F64
+  using T = double;
+#else
+  using T = Tio;
+#endif
+  using R = Real<T>;
+  constexpr int MR = Cfg::MR, G = Cfg::G, CPL = Cfg::CPL, PPW = Cfg::PPW;
+  const int lane = threadIdx.x & 63;
+  const int g = lane % G;
+  const int cls = blockIdx.x * PPW + lane / G;
+  Tio* lt = LT + (size_t)(cls < nA ? cls : nA - 1) * (MR * MR);
+  T x[CPL][MR];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int col = c * G + g;
+    const Tio* src = lt + (size_t)(col < MR ? col : 0) * MR;
+    const bool real_col = col < MR;
+#pragma unroll
+    for (int k = 0; k < MR; ++k) x[c][k] = real_col ? (T)src[k] : T(0);
+  }
+  const T tol2 = R::kEps * R::kEps * T(MR);
+  T nrm[CPL], D[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) D[c] = T(1);
+  int sweeps = 0;
+  bool more = true;
+  while (more && sweeps < max_sweeps) {
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      T a = T(0);
+#pragma unroll
+      for (int r = 0; r < MR; ++r) a = R::fma_(x[c][r], x[c][r], a);
+      nrm[c] = a * D[c];
+    }
+    bool big = false;
+    if constexpr (SQFA_LOCAL_TOURNAMENT && G == 1) {
+      local_rounds<T, MR, CPL, 1>(x, nrm, D, tol2, big);
+    } else {
+      constexpr int CE = z_visits_cfg<G, MR, CPL>() ? CPL - 1 : CPL;
+#pragma unroll
+      for (int c1 = 0; c1 < CE; ++c1) {
+#pragma unroll
+        for (int c2 = c1 + 1; c2 < CE; ++c2) {
+          const T gh = dot_cols<T, MR>(x[c1], x[c2]);
+          T u, ru, k, g2;
+          rot_scaled(nrm[c1], nrm[c2], gh, D[c1], D[c2], tol2, T(1), u, ru, k, g2, big);
+          const T kgh = k * gh, kg2 = k * g2;
+          const T a1 = -(kgh * D[c2]), a2 = kgh * D[c1];
+#pragma unroll
+          for (int r = 0; r < MR; ++r) {
+            const T xp = x[c1][r];
+            x[c1][r] = R::fma_(a1, x[c2][r], xp);
+            x[c2][r] = R::fma_(a2, xp, x[c2][r]);
+          }
+          D[c1] *= u;
+          D[c2] *= u;
+          nrm[c1] -= kg2;
+          nrm[c2] += kg2;
+        }
+      }
+    }
+    constexpr int STATIC_G = sizeof(T) == 4 ? 32 : 16;  // PairCfg::STATIC_G's rule for the arithmetic type used HERE
+    if constexpr (G > 1 && G <= STATIC_G) {
+      cross_rounds_static<T, MR, G, CPL, 1>(x, nrm, D, tol2, big);
+    } else if constexpr (G > STATIC_G) {
+#pragma unroll 1
+      for (int s = 1; s < G; ++s) cross_round<T, MR, CPL, 0, 0, (MR == G * (CPL - 1) + 1)>(x, nrm, D, s, tol2, big);
+    }
+    if constexpr (z_visits_cfg<G, MR, CPL>()) z_visits<T, MR, G, CPL, swizzled_rows_of_8<T, G, MR>(), 0>(x, nrm, D, tol2, big);
+    more = __any(big);
+    ++sweeps;
+  }
+  if (cls < nA) {
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const int col = c * G + g;
+      if (col < MR) {
+        const T dc = R::sqrt_(D[c]);
+        Tio* dst = lt + (size_t)col * MR;
+#pragma unroll
+        for (int r = 0; r < MR; ++r) dst[r] = (Tio)(x[c][r] * dc);
+      }
+    }
+  }
+}
+
+template <typename Cfg>
+hipError_t launch_class_factors(const PairParams& p, hipStream_t stream) {
+  if constexpr (!Cfg::DENSE_FACTOR) {
+    return hipSuccess;
+  } else {
+    using T = typename Cfg::type;
+    using FC = FactorCfg<T, Cfg::MR>;
+    const int blocks = (p.nA + FC::PPW - 1) / FC::PPW;
+    hipLaunchKernelGGL((class_factor_kernel<FC>), dim3(blocks), dim3(64), 0, stream,
+                       static_cast<T*>(const_cast<void*>(p.LT)), p.nA, Cfg::FACTOR_SWEEPS);
+    return hipGetLastError();
+  }
 }
 
 }  // namespace sqfa

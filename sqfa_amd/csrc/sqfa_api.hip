@@ -15,8 +15,12 @@
 namespace sqfa {
 
 // ---- per-configuration launchers (defined in pair_inst.hip translation units) -----------
-#define SQFA_DECL_F32(T, MR, G, CPL, TJ, WV) hipError_t launch_pair_f32_##MR(const PairParams&, hipStream_t);
-#define SQFA_DECL_F64(T, MR, G, CPL, TJ, WV) hipError_t launch_pair_f64_##MR(const PairParams&, hipStream_t);
+#define SQFA_DECL_F32(T, MR, G, CPL, TJ, WV) \
+  hipError_t launch_pair_f32_##MR(const PairParams&, hipStream_t);   \
+  hipError_t launch_factor_f32_##MR(const PairParams&, hipStream_t);
+#define SQFA_DECL_F64(T, MR, G, CPL, TJ, WV) \
+  hipError_t launch_pair_f64_##MR(const PairParams&, hipStream_t);   \
+  hipError_t launch_factor_f64_##MR(const PairParams&, hipStream_t);
 SQFA_CONFIGS_F32(SQFA_DECL_F32)
 SQFA_CONFIGS_F64(SQFA_DECL_F64)
 
@@ -28,6 +32,7 @@ SQFA_CONFIGS2D_F64(SQFA_DECL2D_F64)
 struct Geometry {
   int MR, G, CPL, TJ, TI, WV;  // TJ: widest tile (B classes); a launch may use TJ/2, TJ/4 ... >= WV
   hipError_t (*launch)(const PairParams&, hipStream_t);
+  hipError_t (*factor)(const PairParams&, hipStream_t);  // K0b, the class factor pass (nullptr: the 2-D rows keep triangular factors)
 };
 
 // The geometry table: every whole-column row (pair_kernel.hpp) and every 2-D row (pair_kernel_2d.hpp: GC column lanes x 2
@@ -41,12 +46,12 @@ static bool find_geometry(int m, int dtype, Geometry* out) {
       found = true;
     }
   };
-#define SQFA_ROW_F32(T, MR_, G_, CPL_, TJ_, WV_) consider(SQFA_F32, Geometry{MR_, G_, CPL_, TJ_, 64 / G_, WV_, launch_pair_f32_##MR_});
-#define SQFA_ROW_F64(T, MR_, G_, CPL_, TJ_, WV_) consider(SQFA_F64, Geometry{MR_, G_, CPL_, TJ_, 64 / G_, WV_, launch_pair_f64_##MR_});
+#define SQFA_ROW_F32(T, MR_, G_, CPL_, TJ_, WV_) consider(SQFA_F32, Geometry{MR_, G_, CPL_, TJ_, 64 / G_, WV_, launch_pair_f32_##MR_, launch_factor_f32_##MR_});
+#define SQFA_ROW_F64(T, MR_, G_, CPL_, TJ_, WV_) consider(SQFA_F64, Geometry{MR_, G_, CPL_, TJ_, 64 / G_, WV_, launch_pair_f64_##MR_, launch_factor_f64_##MR_});
 #define SQFA_ROW2D_F32(T, MR_, GC_, CPL_, TJ_, WV_, RS_) \
-  consider(SQFA_F32, Geometry{MR_, 2 * GC_, CPL_, TJ_, 64 / (2 * GC_), WV_, launch_pair2d_f32_##MR_});
+  consider(SQFA_F32, Geometry{MR_, 2 * GC_, CPL_, TJ_, 64 / (2 * GC_), WV_, launch_pair2d_f32_##MR_, nullptr});
 #define SQFA_ROW2D_F64(T, MR_, GC_, CPL_, TJ_, WV_, RS_) \
-  consider(SQFA_F64, Geometry{MR_, 2 * GC_, CPL_, TJ_, 64 / (2 * GC_), WV_, launch_pair2d_f64_##MR_});
+  consider(SQFA_F64, Geometry{MR_, 2 * GC_, CPL_, TJ_, 64 / (2 * GC_), WV_, launch_pair2d_f64_##MR_, nullptr});
   SQFA_CONFIGS_F32(SQFA_ROW_F32)
   SQFA_CONFIGS_F64(SQFA_ROW_F64)
   SQFA_CONFIGS2D_F32(SQFA_ROW2D_F32)
@@ -625,6 +630,10 @@ static int pairwise_impl(const void* A, int nA, const void* B, int nB, int m, in
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(SQFA_ERR_LAUNCH, "cholesky_kernel", e);
+  if (g.factor != nullptr) {  // K0b: orthogonalise the columns of each A-side factor (same stream: after the Cholesky launches)
+    e = g.factor(p, stream);
+    if (e != hipSuccess) return fail(SQFA_ERR_LAUNCH, "class_factor_kernel", e);
+  }
 
   // K1: pair tiles
   EventPair ev{};
