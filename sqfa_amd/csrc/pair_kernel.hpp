@@ -1325,6 +1325,9 @@ __global__ __launch_bounds__(64) void class_factor_kernel(typename Cfg::io_type*
     more = __any(big);
     ++sweeps;
   }
+  // (Writing the columns back sorted by norm was tried -- a numpy emulation with a round-robin tournament gained most of a
+  // sweep on unrelated ill-conditioned pencils -- and changes nothing under this kernel's pairing order: cond 1e3, m=16 / 32,
+  // 6.54 / 7.35 sweeps unsorted, 6.67 / 7.46 ascending, 6.57 / 7.43 descending.  Columns stay where they are.)
   if (cls < nA) {
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
