@@ -231,8 +231,12 @@ int sqfa_gauss_pair_terms(const void *muA, const void *covA, int nA, const void 
  * sqfa_airm_profile(1): every following sqfa_airm_pairwise call brackets its pair tile kernel
  *   with hipEvents recorded on the caller's stream.  sqfa_airm_profile_read synchronises on
  *   those events, returns the summed kernel time [ms] and the number of launches, and
- *   releases them (call it outside any timed region). */
+ *   releases them (call it outside any timed region).
+ * sqfa_airm_class_factor_policy(mode): the class factor pass K0b (pair_kernel.hpp, class_factor_kernel) normally runs
+ *   only for launches with enough pairs to pay for its latency (mode 0, the default); 1 = always (tests: small cases
+ *   through the pass), -1 = never (A/B timing).  Returns the previous mode.  Results agree to rounding either way. */
 int sqfa_airm_set_sweep_counter(unsigned long long *device_counter2);
+int sqfa_airm_class_factor_policy(int mode);
 int sqfa_airm_profile(int enable);
 int sqfa_airm_profile_read(double *tile_kernel_ms_total, int *launches);
 int sqfa_project_profile_read(double *kernel_ms_total, int *launches);  /* same, for sqfa_project_scatters */

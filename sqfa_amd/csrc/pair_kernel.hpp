@@ -58,6 +58,7 @@ struct PairParams {
   int shard_index, shard_count;
   int nbi, nbj;
   int tj;  // B classes per tile in this launch (<= the configuration's TJ, a multiple of its wave count)
+  int factor_mode;  // class factor pass: 0 by pair count (PairCfg::FACTOR_MIN_PAIRS), 1 always, -1 never
   double scale, eps, uniform_weight;
   float scale_f, eps_f, uniform_weight_f;  // the same three, pre-rounded for the float32 kernels (stay in SGPRs)
 };
@@ -817,6 +818,14 @@ struct PairCfg {
 #endif
   static constexpr int FACTOR_SWEEPS = SQFA_FACTOR_SWEEPS >= 0 ? SQFA_FACTOR_SWEEPS : (MR_ >= SQFA_FACTOR_MIN_M ? 2 : 0);
   static constexpr bool DENSE_FACTOR = FACTOR_SWEEPS > 0;
+  // The pass is a handful of lone waves: its duration is one wave's latency whatever the class count (float32: 10 us at
+  // m <= 16, 20 at 17, 32-37 at 20-24, 45 / 76 at 32 / 33, 0.28 / 0.40 ms at 48 / 64), while what it saves is a share of the
+  // pair kernel (m=16 8 %, 17 6 %, 20-24 3 %, 32-64 9-10 %; m=12 2 %).  Launches with fewer pairs (per shard) than this
+  // skip it -- c5 (C=100, m=17: 4 950 pairs, a 0.08 ms kernel) lost 13 % with it, one shard of eight of c3 would lose 3 %.
+  // (float64 pairs cost ~2.5x as much, the pass the same: thresholds / 2.5.)
+  static constexpr long FACTOR_MIN_PAIRS_F32 = MR_ <= 12 ? 600000 : (MR_ <= 16 ? 100000 : (MR_ <= 17 ? 160000 : (MR_ <= 24 ? 250000 :
+                                               (MR_ <= 33 ? 45000 : (MR_ <= 48 ? 40000 : 25000)))));
+  static constexpr long FACTOR_MIN_PAIRS = sizeof(T) == 4 ? FACTOR_MIN_PAIRS_F32 : FACTOR_MIN_PAIRS_F32 * 2 / 5;
   static constexpr bool PACK_LINV = MR_ >= 32;
   static constexpr int LINV_ELEMS = PACK_LINV ? MR_ * (MR_ + 1) / 2 : MR_ * MR_;
   static_assert(G * CPL >= MR, "not enough column slots");
@@ -1241,8 +1250,10 @@ struct FactorCfg {
   using io_type = Tio_;
   static constexpr int MR = MR_;
 #ifndef SQFA_FACTOR_G
-  // (double state: 16 lanes x 3 slots x 48 rows would need 576 VGPRs -- measured 0.9 ms of spills -- so sizes above 33 take 32 lanes)
-  static constexpr int G = MR_ <= 12 ? 4 : (MR_ <= 24 ? 8 : (MR_ <= 33 ? 16 : 32));
+  // measured, C=1000, two double sweeps: m=16 4 lanes (the pair kernel's geometry) 23 us, 8 lanes 14.6, 16 lanes 9.9; m=17 32.5 /
+  // 23.5 / 20.0; m=24 8 lanes 42, 16 lanes 37; m=32 8 lanes 173, 16 lanes 72, 32 lanes 45; m=33 227 / 105 / 76; m=48 with 16
+  // lanes x 3 slots needs 576 VGPRs of double state and spills (0.9 ms), 32 lanes 0.28 ms; m=64 0.40 ms
+  static constexpr int G = MR_ <= 24 ? 16 : 32;
 #else
   static constexpr int G = SQFA_FACTOR_G;
 #endif
@@ -1349,6 +1360,8 @@ hipError_t launch_class_factors(const PairParams& p, hipStream_t stream) {
   } else {
     using T = typename Cfg::type;
     using FC = FactorCfg<T, Cfg::MR>;
+    const long pairs = p.self_mode ? (long)p.nA * (p.nA - 1) / 2 : (long)p.nA * p.nB;
+    if (p.factor_mode < 0 || (p.factor_mode == 0 && pairs / p.shard_count < Cfg::FACTOR_MIN_PAIRS)) return hipSuccess;  // same decision on every shard of a job
     const int blocks = (p.nA + FC::PPW - 1) / FC::PPW;
     hipLaunchKernelGGL((class_factor_kernel<FC>), dim3(blocks), dim3(64), 0, stream,
                        static_cast<T*>(const_cast<void*>(p.LT)), p.nA, Cfg::FACTOR_SWEEPS);

@@ -71,6 +71,7 @@ static int max_dim() {
 
 static thread_local char g_last_error[256] = "";
 static unsigned long long* g_sweep_counter = nullptr;
+static int g_factor_mode = 0;  // sqfa_airm_class_factor_policy
 
 // optional per-launch timing of the pair tile kernel with HIP events on the caller's stream
 struct EventPair { hipEvent_t a, b; };
@@ -475,6 +476,12 @@ int sqfa_airm_set_sweep_counter(unsigned long long* device_counter2) {
   return SQFA_OK;
 }
 
+int sqfa_airm_class_factor_policy(int mode) {
+  const int previous = g_factor_mode;
+  g_factor_mode = mode > 0 ? 1 : (mode < 0 ? -1 : 0);
+  return previous;
+}
+
 int sqfa_airm_profile(int enable) {
   g_profile = enable != 0;
   return SQFA_OK;
@@ -591,6 +598,7 @@ static int pairwise_impl(const void* A, int nA, const void* B, int nB, int m, in
   p.nbi = nbi;
   p.nbj = nbj;
   p.tj = tj;
+  p.factor_mode = g_factor_mode;
   p.scale = scale;
   p.eps = eps;
   p.uniform_weight = uniform_weight;

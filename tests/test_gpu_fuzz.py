@@ -30,6 +30,24 @@ for m in (1, 2, 3, 4, 5, 7, 8, 9, 11, 12, 13, 16, 17, 18, 20, 23, 24, 25, 31, 32
                       int(_rng.integers(0, 2))))
 
 
+@pytest.fixture
+def class_factors_always():
+    """Force the class factor pass (K0b) on: by default it only runs for launches with >= 1e4-1e5 pairs, far more than
+    these cases have (sqfa_airm_class_factor_policy, include/sqfa_hip.h)."""
+    from sqfa_amd import _lib
+    lib = _lib.load()
+    previous = lib.sqfa_airm_class_factor_policy(1)
+    yield
+    lib.sqfa_airm_class_factor_policy(previous)
+
+
+@pytest.mark.parametrize("m,nA,nB,sqrt_mode,weighted,shards,f64", [c for c in CASES if c[0] >= 9])
+def test_random_case_through_class_factor_pass(class_factors_always, m, nA, nB, sqrt_mode, weighted, shards, f64):
+    """The same sweep with the factor pass forced on (sizes whose geometry has one: MR >= 12): ragged class counts, cross
+    mode (the pass touches the A side only), identity-padded sizes, shards."""
+    test_random_case(m, nA, nB, sqrt_mode, weighted, shards, f64)
+
+
 @pytest.mark.parametrize("m,nA,nB,sqrt_mode,weighted,shards,f64", CASES)
 def test_random_case(m, nA, nB, sqrt_mode, weighted, shards, f64):
     from sqfa_amd import _native
@@ -74,7 +92,7 @@ def test_random_case(m, nA, nB, sqrt_mode, weighted, shards, f64):
 
 
 @pytest.mark.parametrize("K,embed", [(16, True), (16, False), (32, True), (8, True)])
-def test_many_random_filter_draws_f32_vs_f64(K, embed):
+def test_many_random_filter_draws_f32_vs_f64(class_factors_always, K, embed):
     """Rare-event guard: the float32 kernel against the float64 kernel on the SQFA / SecondMomentsSQFA feature matrices
     of many random filter draws (C=300 classes: ~45 000 pairs per draw).  A kernel variant tried in round 2 passed
     every other test and still returned ONE wrong pair in ~90 000 for about one draw in a hundred
@@ -111,7 +129,7 @@ def test_many_random_filter_draws_f32_vs_f64(K, embed):
 
 
 @pytest.mark.parametrize("m", [12, 16, 17, 24, 32, 33])
-def test_unrelated_ill_conditioned_classes_f32(m):
+def test_unrelated_ill_conditioned_classes_f32(class_factors_always, m):
     """The other end of the input range from the benchmark's similar classes: classes with nothing in common (random
     eigenvectors, eigenvalues log-uniform over a condition number of 1e4), where the pair sweeps need the most rounds.  The class
     factor pass (K0b) and the float32 stop threshold were tuned on benchmark-like data; this pins their accuracy here,
@@ -137,3 +155,31 @@ def test_unrelated_ill_conditioned_classes_f32(m):
     print(f"m={m}: loss {e_loss:.2e}  distances (max) {e_dist:.2e}  gradient {e_grad:.2e}")
     # measured: loss <= 2.7e-7, distances <= 4.4e-7, gradient <= 2.2e-6 (without the factor pass: 3.5e-7, 4.7e-7, 2.4e-6)
     assert e_loss <= 1e-6 and e_dist <= 2e-6 and e_grad <= 1e-5
+
+
+@pytest.mark.parametrize("m,f64", [(12, False), (16, False), (17, False), (20, False), (32, False), (33, False), (48, False), (64, False),
+                                   (16, True), (17, True), (20, True), (64, True)])
+def test_class_factor_pass_on_and_off_agree(m, f64):
+    """K0b replaces the Cholesky factor of each A-side class by another factor of the same matrix: the result may only
+    move by rounding.  Both policies against each other (and the control's return value)."""
+    from sqfa_amd import _lib, _native
+    lib = _lib.load()
+    rng = np.random.default_rng(7 * m)
+    C = 40 if m <= 33 else 12
+    dtype = torch.float64 if f64 else torch.float32
+    A = torch.tensor(spd(rng, C, m), dtype=dtype, device=DEV)
+    outs = {}
+    first = lib.sqfa_airm_class_factor_policy(-1)
+    try:
+        for mode in (-1, 1):
+            assert lib.sqfa_airm_class_factor_policy(mode) in (-1, 1)
+            outs[mode] = _native.hip_pair_backend(A, None, scale=1.0, eps=1e-6, sqrt_mode=True, weights=None, uniform_weight=1.0,
+                                                  shard=(0, 1), want_loss=True, want_grad=True, want_dist=True, want_eig=False)
+    finally:
+        lib.sqfa_airm_class_factor_policy(first)
+    off, on = outs[-1], outs[1]
+    assert on["nonfinite"].tolist() == [0, 0]
+    ltol, gtol = (1e-12, 1e-10) if f64 else (1e-6, 2e-5)
+    assert abs(on["loss"].item() - off["loss"].item()) <= ltol * abs(off["loss"].item())
+    assert rel_err(on["gradA"].cpu(), off["gradA"].cpu().numpy()) <= gtol
+    assert not torch.equal(on["gradA"], off["gradA"])  # the pass did run (a different factor rounds differently)
