@@ -111,7 +111,13 @@ template <> struct Real<float> {
 #ifndef SQFA_EARLY2_F32
 #define SQFA_EARLY2_F32 3.0e-6f  // 1e-7 until round 3; measured against the float64 kernels: 1e-7 ... 3e-6 identical to three digits, 1e-5 first visible
 #endif
-  static constexpr float kEarly2 = SQFA_EARLY2_F32;  // a sweep in which every cos^2 between columns stays below this is the last one
+  // a sweep in which every cos^2 between columns stays below this is the last one.  3e-6 where the probes against the float64
+  // kernels show no change at all (column lengths >= 12); the short columns of m <= 8 keep 1e-6: at C=10, m=5 the gradient
+  // error moved from 6.0e-7 to 9.1e-7 with 3e-6 (nothing at 1e-6), and those kernels are not where the time goes
+#ifndef SQFA_EARLY2_F32_SHORT
+#define SQFA_EARLY2_F32_SHORT 1.0e-6f
+#endif
+  template <int MR> static constexpr float early2() { return MR >= 12 ? SQFA_EARLY2_F32 : SQFA_EARLY2_F32_SHORT; }
 #ifndef SQFA_RENORM_LOG2
 #define SQFA_RENORM_LOG2 24
 #endif
@@ -130,7 +136,7 @@ template <> struct Real<double> {
 #ifndef SQFA_EARLY2_F64
 #define SQFA_EARLY2_F64 1.0e-15
 #endif
-  static constexpr double kEarly2 = SQFA_EARLY2_F64;
+  template <int MR> static constexpr double early2() { return SQFA_EARLY2_F64; }
   static constexpr double kScaleHi = (double)(1ull << SQFA_RENORM_LOG2), kScaleLo = 1.0 / kScaleHi;
   // v_rcp_f64 seed + one third-order step: 1/x = y (1 + e + e^2 + O(e^3)), e = 1 - x y
   static __device__ __forceinline__ double rcp(double x) {
@@ -290,14 +296,15 @@ __device__ __forceinline__ double wave_uniform(double v) {
 // norms are EXACTLY equal (dh = +0 on both sides): `tie` (+1 on one owner, -1 on the other)
 // breaks that tie antisymmetrically.  Outputs are the identity (u = ru = 1, k = 0) when the
 // columns are already orthogonal to working precision.
-template <typename T>
+// `MR` (the rows a column has in the calling layout) only selects the stop threshold: Real<T>::early2<MR>()
+template <typename T, int MR>
 __device__ __forceinline__ void rot_scaled(T no, T nr, T gh, T Dx, T Dy, T tol2, T tie, T& u, T& ru, T& k, T& g2,
                                            bool& big) {
   using R = Real<T>;
   const T ab = no * nr;
   g2 = gh * gh * (Dx * Dy);
   const bool rot = g2 > tol2 * ab;
-  big = big || (g2 > R::kEarly2 * ab);
+  big = big || (g2 > R::template early2<MR>() * ab);
   const T dh = T(0.5) * (nr - no);
   const T rh = R::rsq(R::fma_(dh, dh, g2));
   const T uu = R::fma_(T(0.5) * R::abs_(dh), rh, T(0.5));
@@ -394,7 +401,7 @@ __device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
       const T nr1 = lane_xor<S>(nrm[cp], s);
       const T Dp = lane_xor<S>(D[cp], s);
       T u1, ru1, k1, g21;
-      rot_scaled(nrm[c], nr1, gh, D[c], Dp, tol2, tie, u1, ru1, k1, g21, big);
+      rot_scaled<T, MR>(nrm[c], nr1, gh, D[c], Dp, tol2, tie, u1, ru1, k1, g21, big);
       const T kgh = k1 * gh, kg2 = k1 * g21;
       {
         const T a = -(kgh * Dp);
@@ -469,7 +476,7 @@ __device__ __forceinline__ void cross_step2(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
     if (PARAM_PRIO) __builtin_amdgcn_s_setprio(SQFA_PARAM_PRIO);
     const T gh = row_total<RS>(dot_cols<T, MR>(x[c], rv[q]));
     T u1, k1, g21;
-    rot_scaled(nrm[c], nr1[q], gh, D[c], Dp[q], tol2, tie, u1, ru1[q], k1, g21, big);
+    rot_scaled<T, MR>(nrm[c], nr1[q], gh, D[c], Dp[q], tol2, tie, u1, ru1[q], k1, g21, big);
     kgh[q] = k1 * gh;
     kg2[q] = k1 * g21;
     if (PARAM_PRIO) __builtin_amdgcn_s_setprio(0);
@@ -605,7 +612,7 @@ __device__ __forceinline__ void local_step2(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
     T u, ru, k, g2;
-    rot_scaled(nrm[ca[q]], nrm[cb[q]], gh[q], D[ca[q]], D[cb[q]], tol2, T(1), u, ru, k, g2, big);
+    rot_scaled<T, MR>(nrm[ca[q]], nrm[cb[q]], gh[q], D[ca[q]], D[cb[q]], tol2, T(1), u, ru, k, g2, big);
     const T kgh = k * gh[q], kg2 = k * g2;
     a1[q] = -(kgh * D[cb[q]]);
     a2[q] = kgh * D[ca[q]];
@@ -1014,7 +1021,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
         for (int c2 = c1 + 1; c2 < CE; ++c2) {
           const T gh = dot_cols<T, MR>(x[c1], x[c2]);
           T u, ru, k, g2;
-          rot_scaled(nrm[c1], nrm[c2], gh, D[c1], D[c2], tol2, T(1), u, ru, k, g2, big);
+          rot_scaled<T, MR>(nrm[c1], nrm[c2], gh, D[c1], D[c2], tol2, T(1), u, ru, k, g2, big);
           const T kgh = k * gh, kg2 = k * g2;
           const T a1 = -(kgh * D[c2]), a2 = kgh * D[c1];
 #pragma unroll
@@ -1309,7 +1316,7 @@ __global__ __launch_bounds__(64) void class_factor_kernel(typename Cfg::io_type*
         for (int c2 = c1 + 1; c2 < CE; ++c2) {
           const T gh = dot_cols<T, MR>(x[c1], x[c2]);
           T u, ru, k, g2;
-          rot_scaled(nrm[c1], nrm[c2], gh, D[c1], D[c2], tol2, T(1), u, ru, k, g2, big);
+          rot_scaled<T, MR>(nrm[c1], nrm[c2], gh, D[c1], D[c2], tol2, T(1), u, ru, k, g2, big);
           const T kgh = k * gh, kg2 = k * g2;
           const T a1 = -(kgh * D[c2]), a2 = kgh * D[c1];
 #pragma unroll

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
         for (int c2 = c1 + 1; c2 < CE; ++c2) {
           const T gh = row_total<RS>(dot_cols<T, MRL>(x[c1], x[c2]));
           T u, ru, k, g2;
-          rot_scaled(nrm[c1], nrm[c2], gh, D[c1], D[c2], tol2, T(1), u, ru, k, g2, big);
+          rot_scaled<T, MRL>(nrm[c1], nrm[c2], gh, D[c1], D[c2], tol2, T(1), u, ru, k, g2, big);
           const T kgh = k * gh, kg2 = k * g2;
           const T a1 = -(kgh * D[c2]), a2 = kgh * D[c1];
 #pragma unroll
