@@ -20,6 +20,9 @@ namespace sqfa {
 hipError_t SQFA_CAT(launch_pair2d_, SQFA_TAG, SQFA_MR)(const PairParams& p, hipStream_t stream) {
   return launch_pair_tiles_2d<PairCfg2D<SQFA_T, SQFA_MR, SQFA_G, SQFA_CPL, SQFA_TJ, SQFA_WAVES, SQFA_RS>>(p, stream);
 }
+hipError_t SQFA_CAT(launch_factor2d_, SQFA_TAG, SQFA_MR)(const PairParams& p, hipStream_t stream) {
+  return launch_class_factors<PairCfg2D<SQFA_T, SQFA_MR, SQFA_G, SQFA_CPL, SQFA_TJ, SQFA_WAVES, SQFA_RS>>(p, stream);
+}
 }  // namespace sqfa
 #else
 // the -D geometry of this translation unit must be a row of the table the API dispatches on

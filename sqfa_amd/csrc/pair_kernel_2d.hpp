@@ -50,6 +50,14 @@ struct PairCfg2D {
   // (float64, 64 registers of state: the backward phase needs ~250 VGPRs, two waves per SIMD is what the compiler reaches)
   static constexpr int MIN_WAVES = SQFA_2D_MIN_WAVES > 0 ? SQFA_2D_MIN_WAVES
                                    : (PEAK <= 72 ? (sizeof(T) == 8 ? 2 : 4) : (PEAK <= 110 ? 3 : (PEAK <= 180 ? 2 : 1)));
+  // class factor pass (pair_kernel.hpp, K0b): the same policy as the whole-column rows
+  // (measured, C=1000, ms per evaluation without -> with: float32 m=40 19.1 -> 17.6; float64 m=24 10.4 -> 10.2, m=32 24.7 -> 23.2,
+  // m=33 38.9 -> 36.2; float64 m=48 at C=300 11.0 -> 12.2 -- its X formation without the skipped zeros costs more than the
+  // half sweep saved -- so that row keeps triangular factors)
+  static constexpr int FACTOR_SWEEPS = SQFA_FACTOR_SWEEPS >= 0 ? SQFA_FACTOR_SWEEPS : ((sizeof(T) == 8 && MR_ >= 48) ? 0 : 2);
+  static constexpr bool DENSE_FACTOR = FACTOR_SWEEPS > 0;
+  static constexpr long FACTOR_MIN_PAIRS_F32 = MR_ <= 33 ? 45000 : (MR_ <= 48 ? 40000 : 25000);
+  static constexpr long FACTOR_MIN_PAIRS = sizeof(T) == 4 ? FACTOR_MIN_PAIRS_F32 : FACTOR_MIN_PAIRS_F32 * 2 / 5;
   static constexpr bool PACK_LINV = MR_ >= 32;
   static constexpr int LINV_ELEMS = PACK_LINV ? MR_ * (MR_ + 1) / 2 : MR_ * MR_;
   static constexpr int LGC = ilog2(GC_), HB = ilog2(RS_);
@@ -234,7 +242,8 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
 #pragma unroll
           for (int c2 = 0; c2 < CF; ++c2) {
             // column (2 c2 + h) GC + g >= 2 c2 GC of the lower triangular L_i: entries k < 2 c2 GC vanish in every lane
-            if (k >= 2 * c2 * GC) acc[c2] = R::fma_(l, xf[c2][k], acc[c2]);
+            // (only without the class factor pass: its factors are dense)
+            if (Cfg::DENSE_FACTOR || k >= 2 * c2 * GC) acc[c2] = R::fma_(l, xf[c2][k], acc[c2]);
           }
         }
 #pragma unroll

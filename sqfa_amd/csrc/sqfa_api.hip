@@ -24,15 +24,19 @@ namespace sqfa {
 SQFA_CONFIGS_F32(SQFA_DECL_F32)
 SQFA_CONFIGS_F64(SQFA_DECL_F64)
 
-#define SQFA_DECL2D_F32(T, MR, GC, CPL, TJ, WV, RS) hipError_t launch_pair2d_f32_##MR(const PairParams&, hipStream_t);
-#define SQFA_DECL2D_F64(T, MR, GC, CPL, TJ, WV, RS) hipError_t launch_pair2d_f64_##MR(const PairParams&, hipStream_t);
+#define SQFA_DECL2D_F32(T, MR, GC, CPL, TJ, WV, RS) \
+  hipError_t launch_pair2d_f32_##MR(const PairParams&, hipStream_t); \
+  hipError_t launch_factor2d_f32_##MR(const PairParams&, hipStream_t);
+#define SQFA_DECL2D_F64(T, MR, GC, CPL, TJ, WV, RS) \
+  hipError_t launch_pair2d_f64_##MR(const PairParams&, hipStream_t); \
+  hipError_t launch_factor2d_f64_##MR(const PairParams&, hipStream_t);
 SQFA_CONFIGS2D_F32(SQFA_DECL2D_F32)
 SQFA_CONFIGS2D_F64(SQFA_DECL2D_F64)
 
 struct Geometry {
   int MR, G, CPL, TJ, TI, WV;  // TJ: widest tile (B classes); a launch may use TJ/2, TJ/4 ... >= WV
   hipError_t (*launch)(const PairParams&, hipStream_t);
-  hipError_t (*factor)(const PairParams&, hipStream_t);  // K0b, the class factor pass (nullptr: the 2-D rows keep triangular factors)
+  hipError_t (*factor)(const PairParams&, hipStream_t);  // K0b, the class factor pass
 };
 
 // The geometry table: every whole-column row (pair_kernel.hpp) and every 2-D row (pair_kernel_2d.hpp: GC column lanes x 2
@@ -49,9 +53,9 @@ static bool find_geometry(int m, int dtype, Geometry* out) {
 #define SQFA_ROW_F32(T, MR_, G_, CPL_, TJ_, WV_) consider(SQFA_F32, Geometry{MR_, G_, CPL_, TJ_, 64 / G_, WV_, launch_pair_f32_##MR_, launch_factor_f32_##MR_});
 #define SQFA_ROW_F64(T, MR_, G_, CPL_, TJ_, WV_) consider(SQFA_F64, Geometry{MR_, G_, CPL_, TJ_, 64 / G_, WV_, launch_pair_f64_##MR_, launch_factor_f64_##MR_});
 #define SQFA_ROW2D_F32(T, MR_, GC_, CPL_, TJ_, WV_, RS_) \
-  consider(SQFA_F32, Geometry{MR_, 2 * GC_, CPL_, TJ_, 64 / (2 * GC_), WV_, launch_pair2d_f32_##MR_, nullptr});
+  consider(SQFA_F32, Geometry{MR_, 2 * GC_, CPL_, TJ_, 64 / (2 * GC_), WV_, launch_pair2d_f32_##MR_, launch_factor2d_f32_##MR_});
 #define SQFA_ROW2D_F64(T, MR_, GC_, CPL_, TJ_, WV_, RS_) \
-  consider(SQFA_F64, Geometry{MR_, 2 * GC_, CPL_, TJ_, 64 / (2 * GC_), WV_, launch_pair2d_f64_##MR_, nullptr});
+  consider(SQFA_F64, Geometry{MR_, 2 * GC_, CPL_, TJ_, 64 / (2 * GC_), WV_, launch_pair2d_f64_##MR_, launch_factor2d_f64_##MR_});
   SQFA_CONFIGS_F32(SQFA_ROW_F32)
   SQFA_CONFIGS_F64(SQFA_ROW_F64)
   SQFA_CONFIGS2D_F32(SQFA_ROW2D_F32)

@@ -158,7 +158,8 @@ def test_unrelated_ill_conditioned_classes_f32(class_factors_always, m):
 
 
 @pytest.mark.parametrize("m,f64", [(12, False), (16, False), (17, False), (20, False), (32, False), (33, False), (48, False), (64, False),
-                                   (16, True), (17, True), (20, True), (64, True)])
+                                   (16, True), (17, True), (20, True), (64, True),
+                                   (40, False), (24, True), (32, True), (33, True)])  # last row: the 2-D lane layouts (float64 m=48 has no pass)
 def test_class_factor_pass_on_and_off_agree(m, f64):
     """K0b replaces the Cholesky factor of each A-side class by another factor of the same matrix: the result may only
     move by rounding.  Both policies against each other (and the control's return value)."""
