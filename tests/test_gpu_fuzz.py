@@ -184,3 +184,32 @@ def test_class_factor_pass_on_and_off_agree(m, f64):
     assert abs(on["loss"].item() - off["loss"].item()) <= ltol * abs(off["loss"].item())
     assert rel_err(on["gradA"].cpu(), off["gradA"].cpu().numpy()) <= gtol
     assert not torch.equal(on["gradA"], off["gradA"])  # the pass did run (a different factor rounds differently)
+
+
+@pytest.mark.parametrize("m", [16, 17, 33])
+def test_non_spd_class_through_class_factor_pass(class_factors_always, m):
+    """A class that is not positive definite (Cholesky breaks down part-way: some columns of its factor are NaN, some are not)
+    must come out of the factor pass as NaN distances for exactly the pairs that touch it -- flagged, never a hang or a fault,
+    and without contaminating the other classes."""
+    from sqfa_amd import _native
+    rng = np.random.default_rng(m)
+    C = 20
+    A = spd(rng, C, m)
+    bad = 7
+    w, Q = np.linalg.eigh(A[bad])
+    w[m // 2] = -0.3                                    # indefinite: the pivot goes negative half-way through the factorisation
+    A[bad] = (Q * w) @ Q.T
+    out = _native.hip_pair_backend(torch.tensor(A, dtype=torch.float32, device=DEV), None, scale=1.0, eps=1e-6, sqrt_mode=True,
+                                   weights=None, uniform_weight=1.0, shard=(0, 1), want_loss=True, want_grad=True,
+                                   want_dist=True, want_eig=False)
+    assert out["nonfinite"].tolist()[0] == C - 1
+    D = out["dist"].cpu().numpy()
+    touched = np.zeros((C, C), bool)
+    touched[bad, :] = touched[:, bad] = True
+    off = ~np.eye(C, dtype=bool)
+    assert np.isnan(D[touched & off]).all() and np.isfinite(D[~touched & off]).all()
+    good = A.copy()
+    good[bad] = A[0]
+    D_ref, _, _ = closed_form.pairwise(good, None, np.ones((C, C)), 1.0, True)
+    keep = ~touched & off
+    assert np.abs(D[keep] - D_ref[keep]).max() <= 5e-5 * D_ref[keep].max()
