@@ -245,6 +245,34 @@ __global__ __launch_bounds__(256) void cholesky_kernel(const T* __restrict__ S, 
     b[idx / m][idx % m] = 0.0;
   }
   __syncthreads();
+#ifndef SQFA_CHOL_ONE_BARRIER
+#define SQFA_CHOL_ONE_BARRIER 1
+#endif
+#if SQFA_CHOL_ONE_BARRIER
+  // Right-looking elimination on the UNSCALED columns, one workgroup barrier per pivot (round 3; three before: pivot, scaled
+  // column, trailing update): step k only reads column k and the pivot, which no later step writes, and subtracts
+  // a[r][k] a[c][k] / a[k][k] from the trailing block; the columns are scaled by 1/sqrt(pivot) once at the end.
+  for (int k = 0; k < m; ++k) {
+    const double akk = a[k][k];
+    // a non-positive or NaN pivot poisons the trailing block: NaN here and everywhere downstream, as with the scaled form
+    double rk = __builtin_amdgcn_rcp(akk);   // hardware estimate + two Newton steps instead of the IEEE divide sequence
+    rk = rk * (2.0 - akk * rk);
+    rk = rk * (2.0 - akk * rk);
+    if (!(akk > 0.0)) rk = __builtin_nan("");
+    const int n = m - k - 1;
+    for (int e = t; e < n * n; e += 256) {
+      const int r = k + 1 + e / n, c2 = k + 1 + e % n;
+      if (c2 <= r) a[r][c2] -= a[r][k] * a[c2][k] * rk;
+    }
+    __syncthreads();
+  }
+  for (int k = t; k < m; k += 256) rd[k] = fast_rsqrt(a[k][k]);
+  __syncthreads();
+  for (int e = t; e < m * m; e += 256) {
+    const int r = e / m, k = e % m;
+    if (k <= r) a[r][k] *= rd[k];  // r == k: akk * rs = sqrt(akk)
+  }
+#else
   for (int k = 0; k < m; ++k) {
     // a non-positive or NaN pivot gives NaN here and everywhere downstream
     const double rs = fast_rsqrt(a[k][k]);
@@ -261,6 +289,7 @@ __global__ __launch_bounds__(256) void cholesky_kernel(const T* __restrict__ S, 
       if (c2 <= r) a[r][c2] -= a[r][k] * a[c2][k];
     }
   }
+#endif
   __syncthreads();
   // inverse X = L^-1, row by row; 4 lanes per column (always inside one wave, so rows only
   // need the wave's own program order, no workgroup barrier)
