@@ -237,6 +237,11 @@ int sqfa_gauss_pair_terms(const void *muA, const void *covA, int nA, const void 
  *   through the pass), -1 = never (A/B timing).  Returns the previous mode.  Results agree to rounding either way. */
 int sqfa_airm_set_sweep_counter(unsigned long long *device_counter2);
 int sqfa_airm_class_factor_policy(int mode);
+/* sqfa_airm_geometry_policy(mode): launches with few pairs run on "small-launch" lane geometries (more lanes per pair, same
+ *   padded sizes: configs.hpp, SQFA_CONFIGS_F32_SMALL); 0 = by pair count (default), 1 = always where such a row exists,
+ *   -1 = never.  Returns the previous mode.  Workspace sizes from sqfa_airm_workspace_bytes hold for every mode; those
+ *   from sqfa_airm_workspace_bytes_sharded for the mode in force when they were queried. */
+int sqfa_airm_geometry_policy(int mode);
 int sqfa_airm_profile(int enable);
 int sqfa_airm_profile_read(double *tile_kernel_ms_total, int *launches);
 int sqfa_project_profile_read(double *kernel_ms_total, int *launches);  /* same, for sqfa_project_scatters */

@@ -109,6 +109,7 @@ PROTOTYPES = {
     "sqfa_airm_set_sweep_counter": (ctypes.c_int, [ctypes.c_void_p]),
     "sqfa_airm_profile": (ctypes.c_int, [ctypes.c_int]),
     "sqfa_airm_class_factor_policy": (ctypes.c_int, [ctypes.c_int]),
+    "sqfa_airm_geometry_policy": (ctypes.c_int, [ctypes.c_int]),
     "sqfa_airm_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), _c_int_p]),
     "sqfa_project_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), _c_int_p]),
 }

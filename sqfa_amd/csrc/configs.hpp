@@ -41,6 +41,24 @@
 #define SQFA_ROW_F32_64(X) X(float, 64, 32, 2, 4, 2)
 #endif
 
+// Small-launch rows (round 3): the same padded sizes with MORE lanes per pair.  A launch with few pairs does not fill the chip
+// -- c2 (C=100: 4 950 pairs) is 78 waves of the one-lane-per-pair m=8 row on 1 024 SIMDs -- so its duration is one wave's
+// latency, and fewer columns per lane means fewer dependent instructions per sweep.  Measured (pair kernel, us):
+//   C=100:  m=8 27.6 -> 14.9 (4 lanes x 2 slots; 2 x 4: 20.6)   m=12 35.9 -> 27.8 (16 x 1; 8 x 2: 30.2)
+//           m=16 60.8 -> 35.3 (16 x 1; 8 x 2: 39.3)              m=17 91.0 -> 67.1 (8 x 3; 16 x 2: 71.9)
+//   C=300:  m=8 30.3 -> 23.9, but m=16 113 -> 147, m=17 176 -> 217;   C=1000: m=8 154 -> 176
+// so a problem runs on these rows only while its pair count (per shard) stays below small_launch_max_pairs(MR).
+#ifndef SQFA_CONFIGS_F32_SMALL
+#define SQFA_CONFIGS_F32_SMALL(X) \
+  X(float, 8, 4, 2, 8, 4)   \
+  X(float, 12, 16, 1, 8, 4) \
+  X(float, 16, 16, 1, 8, 4) \
+  X(float, 17, 8, 3, 8, 4)
+#endif
+// crossovers measured with tools/time_small_launch.py (profiles/r3_small_launch.txt): m <= 8 the small row still wins at 180 k
+// pairs (64.5 vs 73.4 us) and loses at 500 k (176 vs 154); m=9...12 at ~15 k pairs; m=16 / 17 at ~20 k
+constexpr long small_launch_max_pairs(int MR) { return MR <= 8 ? 250000 : (MR <= 12 ? 14000 : 20000); }
+
 #define SQFA_CONFIGS_F32(X) \
   SQFA_ROW_F32_4(X) \
   SQFA_ROW_F32_8(X) \

@@ -28,8 +28,8 @@ hipError_t SQFA_CAT(launch_factor2d_, SQFA_TAG, SQFA_MR)(const PairParams& p, hi
 // the -D geometry of this translation unit must be a row of the table the API dispatches on
 #define SQFA_ROW_MATCHES(T, MR, G, CPL, TJ, WV) \
   || (std::is_same<T, SQFA_T>::value && MR == SQFA_MR && G == SQFA_G && CPL == SQFA_CPL && TJ == SQFA_TJ && WV == SQFA_WAVES)
-static_assert(false SQFA_CONFIGS_F32(SQFA_ROW_MATCHES) SQFA_CONFIGS_F64(SQFA_ROW_MATCHES),
-              "Makefile CONFIGS and configs.hpp disagree");
+static_assert(false SQFA_CONFIGS_F32(SQFA_ROW_MATCHES) SQFA_CONFIGS_F64(SQFA_ROW_MATCHES) SQFA_CONFIGS_F32_SMALL(SQFA_ROW_MATCHES),
+              "Makefile CONFIGS / CONFIGS_SMALL and configs.hpp disagree");
 namespace sqfa {
 hipError_t SQFA_CAT(launch_pair_, SQFA_TAG, SQFA_MR)(const PairParams& p, hipStream_t stream) {
   return launch_pair_tiles<PairCfg<SQFA_T, SQFA_MR, SQFA_G, SQFA_CPL, SQFA_TJ, SQFA_WAVES>>(p, stream);

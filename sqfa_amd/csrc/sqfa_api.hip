@@ -23,6 +23,10 @@ namespace sqfa {
   hipError_t launch_factor_f64_##MR(const PairParams&, hipStream_t);
 SQFA_CONFIGS_F32(SQFA_DECL_F32)
 SQFA_CONFIGS_F64(SQFA_DECL_F64)
+#define SQFA_DECL_F32S(T, MR, G, CPL, TJ, WV) \
+  hipError_t launch_pair_f32s_##MR(const PairParams&, hipStream_t);  \
+  hipError_t launch_factor_f32s_##MR(const PairParams&, hipStream_t);
+SQFA_CONFIGS_F32_SMALL(SQFA_DECL_F32S)
 
 #define SQFA_DECL2D_F32(T, MR, GC, CPL, TJ, WV, RS) \
   hipError_t launch_pair2d_f32_##MR(const PairParams&, hipStream_t); \
@@ -40,8 +44,11 @@ struct Geometry {
 };
 
 // The geometry table: every whole-column row (pair_kernel.hpp) and every 2-D row (pair_kernel_2d.hpp: GC column lanes x 2
-// row lanes per pair, G = 2 GC lanes per pair) of configs.hpp; a problem of size m runs on the smallest MR >= m.
-static bool find_geometry(int m, int dtype, Geometry* out) {
+// row lanes per pair, G = 2 GC lanes per pair) of configs.hpp; a problem of size m runs on the smallest MR >= m.  A launch
+// with few pairs (`pairs` = pairs per shard; < 0: not known, regular rows only) takes the small-launch row of that MR if
+// there is one (configs.hpp, SQFA_CONFIGS_F32_SMALL).  g_geometry_mode: sqfa_airm_geometry_policy.
+static int g_geometry_mode = 0;
+static bool find_geometry(int m, int dtype, long pairs, Geometry* out) {
   bool found = false;
   Geometry best{};
   auto consider = [&](int dt, const Geometry& g) {
@@ -60,8 +67,19 @@ static bool find_geometry(int m, int dtype, Geometry* out) {
   SQFA_CONFIGS_F64(SQFA_ROW_F64)
   SQFA_CONFIGS2D_F32(SQFA_ROW2D_F32)
   SQFA_CONFIGS2D_F64(SQFA_ROW2D_F64)
+  if (found && g_geometry_mode >= 0 && pairs >= 0) {
+    // same padded size, more lanes per pair
+#define SQFA_ROW_F32S(T, MR_, G_, CPL_, TJ_, WV_)                                                                        \
+    if (dtype == SQFA_F32 && best.MR == MR_ && (g_geometry_mode > 0 || pairs < small_launch_max_pairs(MR_)))                \
+      best = Geometry{MR_, G_, CPL_, TJ_, 64 / G_, WV_, launch_pair_f32s_##MR_, launch_factor_f32s_##MR_};
+    SQFA_CONFIGS_F32_SMALL(SQFA_ROW_F32S)
+  }
   if (found) *out = best;
   return found;
+}
+static long pair_count(int nA, int nB, int shard_count) {  // pairs per shard of a call (nB == 0: self mode)
+  const long p = nB == 0 ? (long)nA * (nA - 1) / 2 : (long)nA * nB;
+  return p / (shard_count > 0 ? shard_count : 1);
 }
 
 static int max_dim() {
@@ -515,6 +533,12 @@ int sqfa_airm_class_factor_policy(int mode) {
   return previous;
 }
 
+int sqfa_airm_geometry_policy(int mode) {
+  const int previous = g_geometry_mode;
+  g_geometry_mode = mode > 0 ? 1 : (mode < 0 ? -1 : 0);
+  return previous;
+}
+
 int sqfa_airm_profile(int enable) {
   g_profile = enable != 0;
   return SQFA_OK;
@@ -562,7 +586,7 @@ int sqfa_airm_tiling(int nA, int nB, int m, int dtype, int* tile_i, int* tile_j,
                      int* n_tiles_j, int* padded_m) {
   if (nA < 1 || nB < 0 || m < 1 || (dtype != SQFA_F32 && dtype != SQFA_F64)) return SQFA_ERR_BAD_ARGUMENT;
   Geometry g;
-  if (!find_geometry(m, dtype, &g)) return SQFA_ERR_UNSUPPORTED_M;
+  if (!find_geometry(m, dtype, pair_count(nA, nB, 1), &g)) return SQFA_ERR_UNSUPPORTED_M;  // the geometry of an unsharded call
   const int nBeff = nB == 0 ? nA : nB;
   if (tile_i) *tile_i = g.TI;
   if (tile_j) *tile_j = g.TJ;
@@ -575,10 +599,14 @@ int sqfa_airm_tiling(int nA, int nB, int m, int dtype, int* tile_i, int* tile_j,
 size_t sqfa_airm_workspace_bytes(int nA, int nB, int m, int dtype) {
   int ti, tj, nbi, nbj, mr;
   if (sqfa_airm_tiling(nA, nB, m, dtype, &ti, &tj, &nbi, &nbj, &mr) != SQFA_OK) return 0;
-  Geometry g;
-  find_geometry(m, dtype, &g);
   const int nBeff = nB == 0 ? nA : nB;
-  return layout(nA, nBeff, g, dtype == SQFA_F32 ? 4 : 8, nB == 0 ? 1 : 0).total;
+  // enough for any shard count: the regular row's and the small-launch row's layouts both fit
+  Geometry g;
+  find_geometry(m, dtype, -1, &g);
+  size_t need = layout(nA, nBeff, g, dtype == SQFA_F32 ? 4 : 8, nB == 0 ? 1 : 0).total;
+  find_geometry(m, dtype, 0, &g);
+  need = std::max(need, layout(nA, nBeff, g, dtype == SQFA_F32 ? 4 : 8, nB == 0 ? 1 : 0).total);
+  return need;
 }
 
 static int pairwise_impl(const void* A, int nA, const void* B, int nB, int m, int dtype, double scale,
@@ -595,7 +623,7 @@ static int pairwise_impl(const void* A, int nA, const void* B, int nB, int m, in
   const bool self_mode = (B == nullptr);
   if (self_mode && nA < 2) return fail(SQFA_ERR_BAD_ARGUMENT, "self mode needs at least two classes", hipSuccess);
   Geometry g;
-  if (!find_geometry(m, dtype, &g)) return fail(SQFA_ERR_UNSUPPORTED_M, "matrix size not supported", hipSuccess);
+  if (!find_geometry(m, dtype, pair_count(nA, nB, shard_count), &g)) return fail(SQFA_ERR_UNSUPPORTED_M, "matrix size not supported", hipSuccess);
   const size_t esz = dtype == SQFA_F32 ? 4 : 8;
   const int nBeff = self_mode ? nA : nB;
   // tile width: halve while a shard's launch would leave workgroup slots empty.  Decided from
@@ -718,7 +746,7 @@ size_t sqfa_airm_workspace_bytes_sharded(int nA, int nB, int m, int dtype, int s
   int ti, tj, nbi, nbj, mr;
   if (shard_count < 1 || sqfa_airm_tiling(nA, nB, m, dtype, &ti, &tj, &nbi, &nbj, &mr) != SQFA_OK) return 0;
   Geometry g;
-  find_geometry(m, dtype, &g);
+  find_geometry(m, dtype, pair_count(nA, nB, shard_count), &g);
   const int nBeff = nB == 0 ? nA : nB, self_mode = nB == 0 ? 1 : 0;
   return layout(nA, nBeff, g, dtype == SQFA_F32 ? 4 : 8, self_mode,
                 choose_tile_width(nA, nBeff, g, self_mode, shard_count), shard_count).total;

@@ -48,6 +48,51 @@ def test_random_case_through_class_factor_pass(class_factors_always, m, nA, nB, 
     test_random_case(m, nA, nB, sqrt_mode, weighted, shards, f64)
 
 
+@pytest.fixture
+def regular_rows_only():
+    """Keep small launches on the regular lane geometries: by default these cases (a few hundred pairs) run on the
+    small-launch rows of configs.hpp wherever one exists (sqfa_airm_geometry_policy, include/sqfa_hip.h)."""
+    from sqfa_amd import _lib
+    lib = _lib.load()
+    previous = lib.sqfa_airm_geometry_policy(-1)
+    yield
+    lib.sqfa_airm_geometry_policy(previous)
+
+
+@pytest.mark.parametrize("m,nA,nB,sqrt_mode,weighted,shards,f64", [c for c in CASES if c[0] <= 17 and not c[6]])
+def test_random_case_on_regular_rows(regular_rows_only, m, nA, nB, sqrt_mode, weighted, shards, f64):
+    """The float32 sizes that have a small-launch row, forced onto their regular row (what C=1000 problems run on)."""
+    test_random_case(m, nA, nB, sqrt_mode, weighted, shards, f64)
+
+
+@pytest.mark.parametrize("m", [5, 8, 9, 12, 16, 17])
+def test_small_launch_and_regular_rows_agree(m):
+    """Both lane geometries of a padded size evaluate the same problem: results may differ by rounding only; the workspace
+    size that holds for every policy covers both."""
+    from sqfa_amd import _lib, _native
+    lib = _lib.load()
+    rng = np.random.default_rng(11 * m)
+    C = 30
+    A = torch.tensor(spd(rng, C, m), dtype=torch.float32, device=DEV)
+    outs = {}
+    first = lib.sqfa_airm_geometry_policy(-1)
+    try:
+        for mode in (-1, 1):
+            assert lib.sqfa_airm_geometry_policy(mode) in (-1, 1)
+            assert lib.sqfa_airm_workspace_bytes(C, 0, m, 0) >= lib.sqfa_airm_workspace_bytes_sharded(C, 0, m, 0, 1) > 0
+            outs[mode] = _native.hip_pair_backend(A, None, scale=1.0, eps=1e-6, sqrt_mode=True, weights=None, uniform_weight=1.0,
+                                                  shard=(0, 1), want_loss=True, want_grad=True, want_dist=True, want_eig=True)
+    finally:
+        lib.sqfa_airm_geometry_policy(first)
+    reg, small = outs[-1], outs[1]
+    assert small["nonfinite"].tolist() == [0, 0]
+    assert abs(small["loss"].item() - reg["loss"].item()) <= 2e-6 * abs(reg["loss"].item())
+    assert rel_err(small["gradA"].cpu(), reg["gradA"].cpu().numpy()) <= 2e-5
+    assert rel_err(small["dist"].cpu(), reg["dist"].cpu().numpy()) <= 1e-5
+    assert rel_err(small["eig"].sort(dim=-1).values.cpu(), reg["eig"].sort(dim=-1).values.cpu().numpy()) <= 1e-5
+    assert not torch.equal(small["gradA"], reg["gradA"])  # a different geometry did run
+
+
 @pytest.mark.parametrize("m,nA,nB,sqrt_mode,weighted,shards,f64", CASES)
 def test_random_case(m, nA, nB, sqrt_mode, weighted, shards, f64):
     from sqfa_amd import _native
