@@ -48,16 +48,21 @@
 //           m=16 60.8 -> 35.3 (16 x 1; 8 x 2: 39.3)              m=17 91.0 -> 67.1 (8 x 3; 16 x 2: 71.9)
 //   C=300:  m=8 30.3 -> 23.9, but m=16 113 -> 147, m=17 176 -> 217;   C=1000: m=8 154 -> 176
 // so a problem runs on these rows only while its pair count (per shard) stays below small_launch_max_pairs(MR).
+// (m=20 and m=32 were added from the same kind of measurement, see small_launch_max_pairs.)
 #ifndef SQFA_CONFIGS_F32_SMALL
 #define SQFA_CONFIGS_F32_SMALL(X) \
   X(float, 8, 4, 2, 8, 4)   \
   X(float, 12, 16, 1, 8, 4) \
   X(float, 16, 16, 1, 8, 4) \
-  X(float, 17, 8, 3, 8, 4)
+  X(float, 17, 8, 3, 8, 4)  \
+  X(float, 20, 8, 3, 8, 4)  \
+  X(float, 32, 32, 1, 4, 1)
 #endif
 // crossovers measured with tools/time_small_launch.py (profiles/r3_small_launch.txt): m <= 8 the small row still wins at 180 k
 // pairs (64.5 vs 73.4 us) and loses at 500 k (176 vs 154); m=9...12 at ~15 k pairs; m=16 / 17 at ~20 k
-constexpr long small_launch_max_pairs(int MR) { return MR <= 8 ? 250000 : (MR <= 12 ? 14000 : 20000); }
+// m=20 (8 lanes x 3 slots) 118 -> 86 us at C=50, 121 -> 96 at C=100, 124 -> 110 at C=130, 156 -> 162 at C=200; m=32 (32 lanes x 1
+// slot) 235 -> 115, 249 -> 151, 293 -> 270, 489 -> 539; other candidates lost or gained < 15 % (m=4 4 x 1, m=24 16 x 2, m=33 16 x 3 / 32 x 2): no row
+constexpr long small_launch_max_pairs(int MR) { return MR <= 8 ? 250000 : (MR <= 12 ? 14000 : (MR <= 17 ? 20000 : 12000)); }
 
 #define SQFA_CONFIGS_F32(X) \
   SQFA_ROW_F32_4(X) \
