@@ -15,8 +15,9 @@ the problem is fixed, `value` is whole-job evaluations per second).
 
 Rank 0 prints ONE JSON line.  Extra objects: "roofline" (pair tile kernel; its duration is measured live with
 HIP events on the launch stream in a short pass right AFTER the timed region, which itself runs with profiling
-off), "cpu_baseline" (the oracle's torch-CPU port of the reference op sequence, timed on the host on a bounded
-sample), "prewarm" (what ran before the headline's own warm-up steps), "scaling_c4_pairs" (BASELINE config 4's
+off), "cpu_baseline" (the oracle's torch-CPU port of the reference op sequence: ONE timed full-size evaluation on every
+core the process is entitled to, plus a one-thread figure on a bounded sample), "prewarm" (what ran before the headline's own warm-up steps), "c3_sqfa" (the same configuration with the
+reference's default model, sqfa.model.SQFA: m = K+1 = 17, own roofline), "scaling_c4_pairs" (BASELINE config 4's
 pair stage, m=32, same sharding) and "scaling_c4_closure" (config 4 end to end at every N: class-sharded
 (C,2048,2048) statistics, projection + all-gather + pair shard + all-reduce + backward + gradient all-reduce
 as four captured graphs around the three collectives); N=1 adds "closure" (metric M2 on the headline workload).
@@ -35,6 +36,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector == f32 MFMA dense peak
+FP64_PEAK_TFLOPS = 78.6    # MI355X public specification (FP64 vector = half the FP32 vector rate); the guide's table has no f64 row
 HBM_PEAK_GBS = 8000.0
 PMC_FILE = "r3_pmc_c3.json"   # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary the `traffic` fields quote
 
@@ -332,42 +334,74 @@ def pmc_traffic(kernel, workload, dtype):
         return json.load(fh)["kernels"].get(kernel, {}).get("hbm_bytes_per_launch")
 
 
-def cpu_baseline(S_cpu, scale, C_full, seconds_budget=25.0):
-    """Time the oracle's torch-CPU port of the reference algorithm (all ordered pairs, eigh
-    whitening, batched eigvalsh, autograd) on the first C_s classes of the same workload."""
-    from oracle import reference_path
-    # use the CPUs this process is actually entitled to (cgroup quota), not every hardware thread
-    threads = torch.get_num_threads()
+def _entitled_threads():
+    """CPUs this process may use: the cgroup quota when there is one, not every hardware thread of the host."""
+    threads = os.cpu_count() or 1
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
         if quota != "max":
             threads = max(1, min(threads, int(int(quota) / int(period))))
     except (OSError, ValueError):
         pass
+    try:
+        threads = min(threads, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    return threads
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(S_cpu, scale, C_full):
+    """The oracle's torch-CPU port of the reference algorithm (all ordered pairs, eigh whitening, batched eigvalsh,
+    autograd: oracle/reference_path.py) timed on this box's host cores, SURVEY.md 8(d):
+      * ONE evaluation of the FULL workload (all C classes) on every core the process is entitled to -- `value`;
+      * a one-thread figure on a bounded sample (the first C_s classes; cost ~ C^2, scaled and labelled as such)."""
+    from oracle import reference_path
+    threads = _entitled_threads()
     torch.set_num_threads(threads)
-    # sample size: ~10 s of host work for the default workload (3 evaluations of ~3 s at m <= 17)
-    C_s = min(C_full, 500 if S_cpu.shape[-1] <= 17 else 300)
-    sample = S_cpu[:C_s].clone()
+    m = S_cpu.shape[-1]
     t0 = time.perf_counter()
-    reference_path.pairwise_loss_and_grad(sample[:60], scale=scale)  # warm-up (MKL init)
+    reference_path.pairwise_loss_and_grad(S_cpu[:60].clone(), scale=scale)  # warm-up (MKL init, thread pool)
     t_warm = time.perf_counter() - t0
-    times = []
-    while sum(times) < seconds_budget and len(times) < 3:
-        t0 = time.perf_counter()
-        reference_path.pairwise_loss_and_grad(sample, scale=scale)
-        times.append(time.perf_counter() - t0)
-    t = min(times)
-    # the reference evaluates all C^2 ordered pairs: cost ~ C^2
-    est_full = t * (C_full / C_s) ** 2
+    t0 = time.perf_counter()
+    reference_path.pairwise_loss_and_grad(S_cpu.clone(), scale=scale)       # the full workload, once
+    t_full = time.perf_counter() - t0
+    # one thread: a sample sized for ~15-20 s (the full evaluation would take minutes on one core)
+    C_s = min(C_full, 300 if m <= 17 else 150)
+    torch.set_num_threads(1)
+    sample = S_cpu[:C_s].clone()
+    reference_path.pairwise_loss_and_grad(sample[:40], scale=scale)
+    t0 = time.perf_counter()
+    reference_path.pairwise_loss_and_grad(sample, scale=scale)
+    t_one = time.perf_counter() - t0
+    torch.set_num_threads(threads)
+    est_one = t_one * (C_full / C_s) ** 2
     return {
-        "value": 1.0 / est_full,
+        "value": 1.0 / t_full,
         "unit": "evals/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"oracle/reference_path.py (torch CPU, {threads} threads) on the first {C_s} of {C_full} classes "
-                  f"({C_s * C_s} ordered pairs): {t:.2f} s/eval best of {len(times)}; scaled by (C/C_s)^2 to the full workload "
-                  f"(= {est_full:.1f} s/eval); warm-up {t_warm:.1f} s",
-        "sample_seconds_per_eval": t,
+        "full_size": True,
+        "cpu_model": _cpu_model(),
+        "sample": f"oracle/reference_path.py (torch CPU, {threads} threads = every core this process is entitled to, {_cpu_model()}): "
+                  f"ONE timed evaluation of the full workload, all {C_full} classes ({C_full * C_full} ordered pairs, m={m}): "
+                  f"{t_full:.2f} s; warm-up {t_warm:.1f} s on 60 classes",
+        "seconds_per_eval": t_full,
+        "one_thread": {
+            "value": 1.0 / est_one, "unit": "evals/s", "cores": 1, "full_size": False,
+            "sample": f"1 thread on the first {C_s} of {C_full} classes ({C_s * C_s} ordered pairs): {t_one:.2f} s, scaled by "
+                      f"(C/C_s)^2 to the full workload (= {est_one:.0f} s/eval)",
+            "sample_seconds_per_eval": t_one,
+        },
     }
 
 
@@ -435,6 +469,7 @@ def main():
     ap.add_argument("--no-closure", action="store_true", help="skip the secondary full-closure measurement (N=1)")
     ap.add_argument("--no-c4-pairs", action="store_true", help="skip the second (m=32) pair workload of the scaling curve")
     ap.add_argument("--no-c4-closure", action="store_true", help="skip the class-sharded c4 closure leg of the scaling curve")
+    ap.add_argument("--no-c3-sqfa", action="store_true", help="skip the leg on the reference's default model (SQFA: m = K+1)")
     ap.add_argument("--fit", action="store_true", help="also time model.fit() (metric M3) inside the closure object")
     ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -596,6 +631,28 @@ def main():
     elapsed, kernel_ms, (loss, flags, grad) = time_pair_workload(S, scale, args.warmup, args.steps)
     assert flags.tolist() == [0, 0], f"non-finite distances: {flags.tolist()}"
 
+    # the reference's DEFAULT model (sqfa.model.SQFA, README flow: Calvo-Oller embedding, m = K+1) on the same configuration,
+    # same step, same sharding -- its own roofline next to the headline's
+    c3_sqfa = None
+    if args.workload == "c3" and not args.no_c3_sqfa:
+        S17, scale17 = make_feature_scatters(C, D, K, "sqfa", device, dtype)
+        steps17, warm17 = max(5, min(100, args.steps)), max(2, min(20, args.warmup))
+        sec17, kms17, (loss17, flags17, _g17) = time_pair_workload(S17, scale17, warm17, steps17)
+        assert flags17.tolist() == [0, 0]
+        m17 = S17.shape[1]
+        fl17 = 8.0 * C * (C - 1) * m17 ** 3 / world
+        peak17 = FP32_PEAK_TFLOPS if dtype == torch.float32 else FP64_PEAK_TFLOPS
+        c3_sqfa = {
+            "workload": f"c3-sqfa: C={C} classes, n_dim={D}, n_filters={K}, sqfa (m={m17}: Calvo-Oller embedding, scale 1/2), "
+                        f"{C * (C - 1) // 2} unordered pairs per eval",
+            "value": steps17 / sec17, "unit": "evals/s", "n_gpus": world, "steps": steps17, "warmup": warm17,
+            "ms_per_step": sec17 / steps17 * 1e3, "scaling": "strong", "loss": loss17.item(),
+            "roofline": {"bound": "valu", "achieved": fl17 / (kms17 * 1e-3) / 1e12, "peak": peak17, "unit": "TFLOP/s",
+                         "frac": fl17 / (kms17 * 1e-3) / 1e12 / peak17, "traffic": None, "kernel": "pair_tile_kernel",
+                         "kernel_ms": kms17, "algorithmic_flops_per_launch": fl17},
+        }
+        del S17, _g17
+
     S_cpu = S.detach().cpu() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     # BASELINE config 4 end to end (class-sharded projection + pair shard + collectives), every rank takes part
     c4_closure = None
@@ -610,6 +667,7 @@ def main():
         flops_eval = 8.0 * C * (C - 1) * m ** 3          # 16 m^3 per unordered pair
         flops_launch = flops_eval / world                # each rank's launch covers 1/world of the tiles
         achieved_tf = flops_launch / (kernel_ms * 1e-3) / 1e12
+        peak_tf = FP32_PEAK_TFLOPS if dtype == torch.float32 else FP64_PEAK_TFLOPS
         esz = 4 if dtype == torch.float32 else 8
         bytes_eval = esz * (2 * C * m * m + 1)
         result = {
@@ -637,21 +695,24 @@ def main():
             "roofline": {
                 "bound": "valu",
                 "achieved": achieved_tf,
-                "peak": FP32_PEAK_TFLOPS,
+                "peak": peak_tf,
                 "unit": "TFLOP/s",
-                "frac": achieved_tf / FP32_PEAK_TFLOPS,
+                "frac": achieved_tf / peak_tf,
                 "traffic": pmc_traffic("pair_tile_kernel", args.workload, args.dtype) if world == 1 else None,
                 "traffic_unit": f"bytes per launch (profiles/{PMC_FILE})",
                 "kernel": "pair_tile_kernel",
                 "kernel_ms": kernel_ms,
                 "algorithmic_flops_per_launch": flops_launch,
-                "note": "FP32 compute-bound kernel: the f32 VALU peak equals the f32 MFMA dense peak (157.3 TF); "
+                "note": ("FP32 compute-bound kernel: the f32 VALU peak equals the f32 MFMA dense peak (157.3 TF); " if dtype == torch.float32 else
+                         "FP64 compute-bound kernel: peak = the f64 vector rate, 78.6 TF (public specification: half the f32 vector rate); ") +
                         "algorithmic flops = 16*m^3 per unordered pair (SURVEY.md 8d). Algorithmic HBM traffic is "
                         f"{bytes_eval / 1e6:.2f} MB per eval = {bytes_eval / (kernel_ms * 1e-3) / 1e9:.1f} GB/s, "
                         f"{bytes_eval / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS * 100:.3f}% of the 8 TB/s HBM roofline",
             },
         }
         result["prewarm"] = prewarm
+        if c3_sqfa is not None:
+            result["c3_sqfa"] = c3_sqfa
         if c4_pairs is not None:
             result["scaling_c4_pairs"] = c4_pairs
         if c4_closure is not None:

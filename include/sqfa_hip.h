@@ -61,11 +61,32 @@ const char *sqfa_hip_last_error(void); /* text of the last HIP error seen by thi
 int sqfa_airm_tiling(int nA, int nB, int m, int dtype,
                      int *tile_i, int *tile_j, int *n_tiles_i, int *n_tiles_j, int *padded_m);
 
-/* Bytes of device workspace sqfa_airm_pairwise needs for this problem with ANY shard_count (0 on error). */
+/* Bytes of device workspace sqfa_airm_pairwise[_opt] needs for this problem with ANY shard_count and ANY options (0 on error). */
 size_t sqfa_airm_workspace_bytes(int nA, int nB, int m, int dtype);
-/* The same for calls with this shard_count only (the tile width, hence the slab, depends on it):
- * at C=1000, m=16 55 MB for shard_count 1 (the slab holds exactly the tiles a shard owns) instead of the bound above. */
-size_t sqfa_airm_workspace_bytes_sharded(int nA, int nB, int m, int dtype, int shard_count);
+/* The same for calls with this shard_count and geometry policy only (the lane geometry and the tile width, hence the slab,
+ * depend on them): at C=1000, m=16 55 MB for shard_count 1 (the slab holds exactly the tiles a shard owns) instead of the
+ * bound above.  geometry_policy: as in sqfa_airm_options (0 for sqfa_airm_pairwise). */
+size_t sqfa_airm_workspace_bytes_sharded(int nA, int nB, int m, int dtype, int shard_count, int geometry_policy);
+
+/* Per-call options of sqfa_airm_pairwise_opt / sqfa_airm_eigenvalues_backward (NULL = all defaults).  There is no
+ * process-wide policy state in the library: what a call does depends on its arguments only.
+ *   geometry_policy      launches with few pairs run on "small-launch" lane geometries (more lanes per pair, same padded
+ *                        sizes: configs.hpp, SQFA_CONFIGS_F32_SMALL): 0 = by pair count (default), 1 = wherever such a row
+ *                        exists, -1 = never (tests run both kinds of row; A/B timing)
+ *   class_factor_policy  the class factor pass K0b (pair_kernel.hpp, class_factor_kernel) runs for launches with enough
+ *                        pairs to pay for its latency: 0 = by pair count (default), 1 = always, -1 = never.  Results agree
+ *                        to rounding either way; every shard of a job must pass the same value.
+ *   sweep_counter        NULL, or a device buffer of two uint64 {sum of Jacobi sweeps, number of wave rounds} the tile
+ *                        kernel adds to atomically (introspection for benchmarks)
+ *   mean_metric_policy   when the factor pass runs, sizes up to 33 orthogonalise the factor columns in the metric of the MEAN
+ *                        class (class_factor_mean_kernel: fewer sweeps for classes that share a dominant covariance):
+ *                        0 = yes (default), -1 = plain inner product (A/B timing, tests) */
+typedef struct sqfa_airm_options {
+  int geometry_policy;
+  int class_factor_policy;
+  unsigned long long *sweep_counter;
+  int mean_metric_policy;
+} sqfa_airm_options;
 
 /*
  * Pairwise affine-invariant distances between two batches of SPD matrices, the
@@ -107,6 +128,15 @@ int sqfa_airm_pairwise(const void *A, int nA, const void *B, int nB, int m, int 
                        void *loss_out, void *gradA_out, void *gradB_out,
                        void *dist_out, void *eig_out, int *nonfinite_out,
                        void *workspace, size_t workspace_bytes, void *stream);
+/* The same call with explicit options (NULL = sqfa_airm_pairwise). */
+int sqfa_airm_pairwise_opt(const void *A, int nA, const void *B, int nB, int m, int dtype,
+                           double scale, double eps, int sqrt_mode,
+                           const void *pair_weights, double uniform_weight,
+                           int shard_index, int shard_count,
+                           void *loss_out, void *gradA_out, void *gradB_out,
+                           void *dist_out, void *eig_out, int *nonfinite_out,
+                           void *workspace, size_t workspace_bytes, void *stream,
+                           const sqfa_airm_options *options);
 
 /*
  * Backward of the generalized eigenvalues themselves (the reference's generalized_eigenvalues,
@@ -120,11 +150,13 @@ int sqfa_airm_pairwise(const void *A, int nA, const void *B, int nB, int m, int 
  *                sorts the eigenvalues scatters its upstream gradient back through the permutation)
  *   gradA_out (nA,m,m), gradB_out (nB,m,m; cross mode); SELF mode (B NULL, nB 0): eig_weights[j,i,k]
  *                weighs the mirrored value 1/lambda_k and the result is the gradient wrt the shared batch.
- *   workspace as for sqfa_airm_pairwise.
+ *   workspace as for sqfa_airm_pairwise; options: those of the call that produced eig_out (the column order depends on
+ *   the lane geometry), NULL = defaults.
  */
 int sqfa_airm_eigenvalues_backward(const void *A, int nA, const void *B, int nB, int m, int dtype,
                                    const void *eig_weights, void *gradA_out, void *gradB_out,
-                                   void *workspace, size_t workspace_bytes, void *stream);
+                                   void *workspace, size_t workspace_bytes, void *stream,
+                                   const sqfa_airm_options *options);
 
 /*
  * T_c = Psi_c F^T for c = 0..C-1: the streaming half of the projection S_c = F Psi_c F^T of the
@@ -224,24 +256,36 @@ int sqfa_gauss_pair_terms(const void *muA, const void *covA, int nA, const void 
                           int m, int dtype, const void *gQ, const void *gLD, void *Q_out, void *LD_out,
                           void *gmuA_out, void *gcovA_out, void *stream);
 
+/*
+ * Matrix functions of SPD matrices, f(S) = Q f(Lambda) Q^T per class, and their backward -- spd_log and spd_sqrt of the
+ * reference (src/sqfa/linalg.py:165-183, 121-141: torch.linalg.eigh + einsum), as used by log_euclidean[_sq]
+ * (src/sqfa/distances.py:92-138).  The eigen-decomposition is one-sided Jacobi, run to convergence, on the Cholesky
+ * factor of each class (S = L L^T, L V = Q Sigma  =>  lambda = sigma^2 with the relative accuracy log needs), in double
+ * whatever the dtype; results are bitwise reproducible.
+ *   S (n,m,m) dtype, F_out (n,m,m) dtype or NULL; U_out (n,m,m) and lam_out (n,m): FLOAT64, eigenvectors as columns,
+ *   eigenvalues unsorted -- what sqfa_spd_function_backward needs (a non-SPD class yields NaN there and in F_out)
+ *   kind: SQFA_SPD_LOG, SQFA_SPD_SQRT, SQFA_SPD_INV_SQRT (the symmetric inverse root)
+ *   workspace: sqfa_spd_function_workspace_bytes(n, m, dtype) bytes; m <= sqfa_hip_max_dim()
+ * sqfa_spd_function_backward: gradS_out (n,m,m) dtype = Q [(Q^T sym(G) Q) o Gamma] Q^T for the upstream gradient
+ *   G (n,m,m) dtype wrt F (Daleckii-Krein; Gamma = divided differences of f, evaluated in forms that stay finite for
+ *   repeated eigenvalues, where torch's eigh backward -- the reference's autograd -- returns inf / NaN).
+ */
+#define SQFA_SPD_LOG 0
+#define SQFA_SPD_SQRT 1
+#define SQFA_SPD_INV_SQRT 2
+size_t sqfa_spd_function_workspace_bytes(int n, int m, int dtype);
+int sqfa_spd_function(const void *S, int n, int m, int dtype, int kind, void *F_out, double *U_out, double *lam_out,
+                      void *workspace, size_t workspace_bytes, void *stream);
+int sqfa_spd_function_backward(const double *U, const double *lam, const void *G, int n, int m, int dtype, int kind,
+                               void *gradS_out, void *stream);
+
 /* Introspection (benchmarks / development; not needed by a reference-side binding).
  *
- * sqfa_airm_set_sweep_counter: register a device buffer of two uint64 {sum of Jacobi sweeps,
- *   number of wave rounds}; the tile kernel adds to it atomically.  NULL disables.
  * sqfa_airm_profile(1): every following sqfa_airm_pairwise call brackets its pair tile kernel
  *   with hipEvents recorded on the caller's stream.  sqfa_airm_profile_read synchronises on
  *   those events, returns the summed kernel time [ms] and the number of launches, and
- *   releases them (call it outside any timed region).
- * sqfa_airm_class_factor_policy(mode): the class factor pass K0b (pair_kernel.hpp, class_factor_kernel) normally runs
- *   only for launches with enough pairs to pay for its latency (mode 0, the default); 1 = always (tests: small cases
- *   through the pass), -1 = never (A/B timing).  Returns the previous mode.  Results agree to rounding either way. */
-int sqfa_airm_set_sweep_counter(unsigned long long *device_counter2);
-int sqfa_airm_class_factor_policy(int mode);
-/* sqfa_airm_geometry_policy(mode): launches with few pairs run on "small-launch" lane geometries (more lanes per pair, same
- *   padded sizes: configs.hpp, SQFA_CONFIGS_F32_SMALL); 0 = by pair count (default), 1 = always where such a row exists,
- *   -1 = never.  Returns the previous mode.  Workspace sizes from sqfa_airm_workspace_bytes hold for every mode; those
- *   from sqfa_airm_workspace_bytes_sharded for the mode in force when they were queried. */
-int sqfa_airm_geometry_policy(int mode);
+ *   releases them (call it outside any timed region).  The switch is an atomic flag; it changes what is
+ *   RECORDED around a launch, never which kernel runs. */
 int sqfa_airm_profile(int enable);
 int sqfa_airm_profile_read(double *tile_kernel_ms_total, int *launches);
 int sqfa_project_profile_read(double *kernel_ms_total, int *launches);  /* same, for sqfa_project_scatters */

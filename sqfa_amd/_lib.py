@@ -20,6 +20,20 @@ STATUS_TEXT = {
     -4: "HIP launch failed",
 }
 
+class AirmOptions(ctypes.Structure):
+    """sqfa_airm_options (include/sqfa_hip.h): per-call policies of sqfa_airm_pairwise_opt."""
+    _fields_ = [("geometry_policy", ctypes.c_int), ("class_factor_policy", ctypes.c_int),
+                ("sweep_counter", ctypes.c_void_p), ("mean_metric_policy", ctypes.c_int)]
+
+
+_PAIRWISE_ARGS = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                  ctypes.c_double, ctypes.c_double, ctypes.c_int,
+                  ctypes.c_void_p, ctypes.c_double,
+                  ctypes.c_int, ctypes.c_int,
+                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                  ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+
 # every symbol include/sqfa_hip.h declares: name -> (restype, argtypes)
 _c_int_p = ctypes.POINTER(ctypes.c_int)
 PROTOTYPES = {
@@ -29,21 +43,14 @@ PROTOTYPES = {
     "sqfa_hip_last_error": (ctypes.c_char_p, []),
     "sqfa_airm_tiling": (ctypes.c_int, [ctypes.c_int] * 4 + [_c_int_p] * 5),
     "sqfa_airm_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),
-    "sqfa_airm_workspace_bytes_sharded": (ctypes.c_size_t, [ctypes.c_int] * 5),
-    "sqfa_airm_pairwise": (
-        ctypes.c_int,
-        [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-         ctypes.c_double, ctypes.c_double, ctypes.c_int,
-         ctypes.c_void_p, ctypes.c_double,
-         ctypes.c_int, ctypes.c_int,
-         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-         ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p],
-    ),
+    "sqfa_airm_workspace_bytes_sharded": (ctypes.c_size_t, [ctypes.c_int] * 6),
+    "sqfa_airm_pairwise": (ctypes.c_int, list(_PAIRWISE_ARGS)),
+    "sqfa_airm_pairwise_opt": (ctypes.c_int, list(_PAIRWISE_ARGS) + [ctypes.POINTER(AirmOptions)]),
     "sqfa_airm_eigenvalues_backward": (
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p],
+         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+         ctypes.POINTER(AirmOptions)],
     ),
     "sqfa_gauss_pair_terms": (
         ctypes.c_int,
@@ -106,10 +113,18 @@ PROTOTYPES = {
         [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
          ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p],
     ),
-    "sqfa_airm_set_sweep_counter": (ctypes.c_int, [ctypes.c_void_p]),
+    "sqfa_spd_function_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
+    "sqfa_spd_function": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p],
+    ),
+    "sqfa_spd_function_backward": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+         ctypes.c_void_p, ctypes.c_void_p],
+    ),
     "sqfa_airm_profile": (ctypes.c_int, [ctypes.c_int]),
-    "sqfa_airm_class_factor_policy": (ctypes.c_int, [ctypes.c_int]),
-    "sqfa_airm_geometry_policy": (ctypes.c_int, [ctypes.c_int]),
     "sqfa_airm_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), _c_int_p]),
     "sqfa_project_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), _c_int_p]),
 }

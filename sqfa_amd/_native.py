@@ -31,6 +31,41 @@ def max_dim():
     return _lib.load().sqfa_hip_max_dim()
 
 
+# Per-call policies of the pair kernels (sqfa_airm_options, include/sqfa_hip.h), read at every launch -- from whichever
+# thread launches (the autograd engine runs backward passes on its own).  The library itself holds no policy state.
+#   geometry      0 small-launch lane geometries by pair count (default), 1 wherever one exists, -1 never
+#   class_factor  0 class factor pass K0b by pair count (default), 1 always, -1 never
+#   sweep_counter None, or an int64 CUDA tensor of two elements {sum of Jacobi sweeps, wave rounds} the kernel adds to
+#   mean_metric   0 the factor pass works in the metric of the mean class where it can (default), -1 plain inner product
+POLICY = {"geometry": 0, "class_factor": 0, "sweep_counter": None, "mean_metric": 0}
+
+
+class policies:
+    """with policies(geometry=-1, class_factor=1): ...   (tests, A/B timing; restores the previous values)"""
+
+    def __init__(self, **kw):
+        unknown = set(kw) - set(POLICY)
+        if unknown:
+            raise TypeError(f"unknown policy {sorted(unknown)}")
+        self.kw = kw
+
+    def __enter__(self):
+        self.saved = dict(POLICY)
+        POLICY.update(self.kw)
+        return self
+
+    def __exit__(self, *exc):
+        POLICY.clear()
+        POLICY.update(self.saved)
+        return False
+
+
+def _options():
+    cnt = POLICY["sweep_counter"]
+    return _lib.AirmOptions(int(POLICY["geometry"]), int(POLICY["class_factor"]),
+                            ctypes.c_void_p(cnt.data_ptr()) if cnt is not None else None, int(POLICY["mean_metric"]))
+
+
 def hip_pair_backend(A, B, *, scale, eps, sqrt_mode, weights, uniform_weight, shard,
                      want_loss, want_grad, want_dist, want_eig, out_loss=None, out_gradA=None):
     """Run sqfa_airm_pairwise on the current stream.  A (nA,m,m); B (nB,m,m) or None (self).
@@ -56,7 +91,8 @@ def hip_pair_backend(A, B, *, scale, eps, sqrt_mode, weights, uniform_weight, sh
         raise NotImplementedError(
             f"matrix size {m} exceeds the largest size the native kernels handle ({lib.sqfa_hip_max_dim()})"
         )
-    nbytes = lib.sqfa_airm_workspace_bytes_sharded(nA, nB, m, code, int(shard[1]))
+    opts = _options()
+    nbytes = lib.sqfa_airm_workspace_bytes_sharded(nA, nB, m, code, int(shard[1]), opts.geometry_policy)
     if nbytes == 0:
         raise _lib.NativeLibraryError("sqfa_airm_workspace_bytes rejected the problem shape")
     dev = A.device
@@ -79,15 +115,15 @@ def hip_pair_backend(A, B, *, scale, eps, sqrt_mode, weights, uniform_weight, sh
             if tuple(weights.shape) != (nA, nBe):
                 raise ValueError("pair weights must have shape (nA, nB)")
         stream = torch.cuda.current_stream(dev).cuda_stream
-        status = lib.sqfa_airm_pairwise(
+        status = lib.sqfa_airm_pairwise_opt(
             _ptr(A), nA, _ptr(B), nB, m, code,
             float(scale), float(eps), int(bool(sqrt_mode)),
             _ptr(weights), float(uniform_weight),
             int(shard[0]), int(shard[1]),
             _ptr(loss), _ptr(gradA), _ptr(gradB), _ptr(dist), _ptr(eig), _ptr(nonfinite),
-            _ptr(ws), nbytes, ctypes.c_void_p(stream),
+            _ptr(ws), nbytes, ctypes.c_void_p(stream), ctypes.byref(opts),
         )
-    _lib.check(status, "sqfa_airm_pairwise")
+    _lib.check(status, "sqfa_airm_pairwise_opt")
     return {"loss": loss, "gradA": gradA, "gradB": gradB, "dist": dist, "eig": eig, "nonfinite": nonfinite}
 
 
@@ -177,8 +213,9 @@ def hip_eigenvalues_backward(A, B, eig_weights):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=A.device)
         gA, gB = torch.empty_like(A), torch.empty_like(B)
         stream = torch.cuda.current_stream(A.device).cuda_stream
+        opts = _options()   # the policies of the forward call: the kernel's eigenvalue order depends on the lane geometry
         status = lib.sqfa_airm_eigenvalues_backward(_ptr(A), nA, _ptr(B), nB, m, code, _ptr(W), _ptr(gA), _ptr(gB),
-                                                    _ptr(ws), nbytes, ctypes.c_void_p(stream))
+                                                    _ptr(ws), nbytes, ctypes.c_void_p(stream), ctypes.byref(opts))
     _lib.check(status, "sqfa_airm_eigenvalues_backward")
     return gA, gB
 
@@ -290,9 +327,69 @@ class GaussPairTerms(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------
+# per-class matrix functions (spd_log / spd_sqrt: log_euclidean's building block)
+
+SPD_LOG, SPD_SQRT, SPD_INV_SQRT = 0, 1, 2
+
+
+def spd_function_supported(M):
+    return (M.is_cuda and M.dtype in (torch.float32, torch.float64) and M.dim() >= 2 and M.shape[-1] == M.shape[-2]
+            and 1 <= M.shape[-1] <= max_dim() and M.numel() > 0)
+
+
+class SpdFunction(torch.autograd.Function):
+    """f(S) = Q f(Lambda) Q^T for a batch (n,m,m) of SPD matrices through sqfa_spd_function (Cholesky + one-sided Jacobi
+    per class, double inside), differentiable through sqfa_spd_function_backward (Daleckii-Krein).  Replaces the
+    reference's torch.linalg.eigh + einsum (src/sqfa/linalg.py:121-141, 165-183) and eigh's autograd backward."""
+
+    @staticmethod
+    def forward(ctx, S, kind):
+        lib = _lib.load()
+        S3 = S.detach().contiguous()
+        n, m = S3.shape[0], S3.shape[-1]
+        code = _dtype_code(S3)
+        nbytes = lib.sqfa_spd_function_workspace_bytes(n, m, code)
+        if nbytes == 0:
+            raise _lib.NativeLibraryError("sqfa_spd_function_workspace_bytes rejected the problem shape")
+        dev = S3.device
+        with torch.cuda.device(dev):
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            F = torch.empty_like(S3)
+            U = torch.empty((n, m, m), dtype=torch.float64, device=dev)
+            lam = torch.empty((n, m), dtype=torch.float64, device=dev)
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(lib.sqfa_spd_function(_ptr(S3), n, m, code, int(kind), _ptr(F), _ptr(U), _ptr(lam), _ptr(ws), nbytes, stream),
+                       "sqfa_spd_function")
+        ctx.save_for_backward(U, lam)
+        ctx.kind = int(kind)
+        return F
+
+    @staticmethod
+    def backward(ctx, gF):
+        U, lam = ctx.saved_tensors
+        lib = _lib.load()
+        G = gF.detach().contiguous()
+        n, m = G.shape[0], G.shape[-1]
+        with torch.cuda.device(G.device):
+            gS = torch.empty_like(G)
+            stream = ctypes.c_void_p(torch.cuda.current_stream(G.device).cuda_stream)
+            _lib.check(lib.sqfa_spd_function_backward(_ptr(U), _ptr(lam), _ptr(G), n, m, _dtype_code(G), ctx.kind, _ptr(gS), stream),
+                       "sqfa_spd_function_backward")
+        return gS, None
+
+
+def spd_function(M, kind):
+    """(..., m, m) -> (..., m, m) on the native kernels (the caller has checked spd_function_supported)."""
+    lead = M.shape[:-2]
+    out = SpdFunction.apply(M.reshape(-1, M.shape[-2], M.shape[-1]), kind)
+    return out.reshape(*lead, M.shape[-2], M.shape[-1])
+
+
+# ------------------------------------------------------------------------------------------
 # projection of the class scatter matrices (the HBM-bound stage around the pair kernel)
 
 
+_symmetry_check_warned = False
 _symmetry_checked = {}   # id(tensor) -> (weakref to the tensor, _version, verdict): dies with the tensor, never reused by another
 
 
@@ -322,8 +419,14 @@ def _is_symmetric_batch(scatters):
                 asym = torch.maximum(asym, (blk - blk.transpose(-2, -1)).abs().amax())
                 peak = torch.maximum(peak, blk.abs().amax())
             ok = bool(asym <= tol * peak)
-    except Exception:   # the check must never take the fit down: the torch expression handles every input
+    except Exception as err:   # the check must never take the fit down: the torch expression handles every input
         ok = False
+        global _symmetry_check_warned
+        if not _symmetry_check_warned:
+            _symmetry_check_warned = True
+            import warnings
+            warnings.warn(f"sqfa_amd: the symmetry check of the scatter matrices itself failed ({err!r}); this tensor keeps the "
+                          "general torch projection (slower, same results)")
     key = id(scatters)
     try:
         ref = weakref.ref(scatters, lambda _r, k=key: _symmetry_checked.pop(k, None))

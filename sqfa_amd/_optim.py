@@ -241,9 +241,18 @@ class ShardedClosure:
         eager=True runs the stages as plain launches even after the capture (profiling passes: the library's HIP
         event records around its kernels happen at launch time, which a graph replay does not repeat)."""
         if eager:
+            # The stage functions REBIND box["st"] / box["grad"] / box["packed"] to fresh tensors, while captured graphs keep
+            # writing into the tensors bound at capture time (and the eager collectives between the graphs read the box).
+            # An eager pass after the capture therefore works on its own bindings, which are dropped again afterwards:
+            # the next replay must find the capture-time tensors (ADVICE r3: it all-reduced and returned the stale eager ones).
+            saved = dict(self.box) if self.state == "on" else None
             for stage in self.stages:
                 stage()
-            return self.box["packed"], self.box["grad"]
+            out = self.box["packed"], self.box["grad"]
+            if saved is not None:
+                self.box.clear()
+                self.box.update(saved)
+            return out
         if self.state == "warmup" and self.calls >= GRAPH_WARMUP_CLOSURES:
             try:
                 self._capture()

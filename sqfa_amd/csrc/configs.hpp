@@ -58,11 +58,19 @@
   X(float, 20, 8, 3, 8, 4)  \
   X(float, 32, 32, 1, 4, 1)
 #endif
+#ifndef SQFA_CONFIGS_F64_SMALL
+#define SQFA_CONFIGS_F64_SMALL(X) \
+  X(double, 8, 2, 4, 8, 4)
+#endif
 // crossovers measured with tools/time_small_launch.py (profiles/r3_small_launch.txt): m <= 8 the small row still wins at 180 k
 // pairs (64.5 vs 73.4 us) and loses at 500 k (176 vs 154); m=9...12 at ~15 k pairs; m=16 / 17 at ~20 k
 // m=20 (8 lanes x 3 slots) 118 -> 86 us at C=50, 121 -> 96 at C=100, 124 -> 110 at C=130, 156 -> 162 at C=200; m=32 (32 lanes x 1
 // slot) 235 -> 115, 249 -> 151, 293 -> 270, 489 -> 539; other candidates lost or gained < 15 % (m=4 4 x 1, m=24 16 x 2, m=33 16 x 3 / 32 x 2): no row
 constexpr long small_launch_max_pairs(int MR) { return MR <= 8 ? 250000 : (MR <= 12 ? 14000 : (MR <= 17 ? 20000 : 12000)); }
+#ifndef SQFA_SMALL_MAX_PAIRS_F64_8
+#define SQFA_SMALL_MAX_PAIRS_F64_8 120000
+#endif
+constexpr long small_launch_max_pairs_f64(int MR) { return SQFA_SMALL_MAX_PAIRS_F64_8; }
 
 #define SQFA_CONFIGS_F32(X) \
   SQFA_ROW_F32_4(X) \
@@ -80,8 +88,10 @@ constexpr long small_launch_max_pairs(int MR) { return MR <= 8 ? 250000 : (MR <=
 #ifndef SQFA_ROW_F64_4
 #define SQFA_ROW_F64_4(X) X(double, 4, 1, 4, 8, 4)
 #endif
+// round 4 (profiles/r4_pairs_fewer_lanes.txt): one lane per pair -- no cross-lane traffic at all, 240 VGPRs, two waves per
+// SIMD -- 0.322 -> 0.268 ms at C=1000; the previous 2 lanes x 4 slots stay as the small-launch row below
 #ifndef SQFA_ROW_F64_8
-#define SQFA_ROW_F64_8(X) X(double, 8, 2, 4, 8, 4)
+#define SQFA_ROW_F64_8(X) X(double, 8, 1, 8, 8, 4)
 #endif
 #ifndef SQFA_ROW_F64_12
 #define SQFA_ROW_F64_12(X) X(double, 12, 4, 3, 8, 4)

@@ -59,6 +59,7 @@ struct PairParams {
   int nbi, nbj;
   int tj;  // B classes per tile in this launch (<= the configuration's TJ, a multiple of its wave count)
   int factor_mode;  // class factor pass: 0 by pair count (PairCfg::FACTOR_MIN_PAIRS), 1 always, -1 never
+  const double* mean_linv;  // Lbar^-1 of the mean A class (MR x MR doubles, identity padded) for the mean-metric factor pass, or nullptr
   double scale, eps, uniform_weight;
   float scale_f, eps_f, uniform_weight_f;  // the same three, pre-rounded for the float32 kernels (stay in SGPRs)
 };
@@ -564,7 +565,10 @@ template <typename T, int G, int MR> constexpr bool paired_steps() {
 #ifndef SQFA_PAIRED_G16
 #define SQFA_PAIRED_G16 0
 #endif
-  return (G == 4 && MR >= 16) || G == 8 || (SQFA_PAIRED_G16 && G == 16);
+#ifndef SQFA_PAIRED_G2
+#define SQFA_PAIRED_G2 0  // round 4 A/B rows (2 lanes x 8 / 9 slots): profiles/r4_pairs_fewer_lanes.txt
+#endif
+  return (G == 4 && MR >= 16) || G == 8 || (SQFA_PAIRED_G16 && G == 16) || (SQFA_PAIRED_G2 && G == 2);
 }
 
 // LONE: -1 = derived from the sizes (whole columns per lane: MR is the matrix size); 0 / 1 = given (2-D layouts: MR is the
@@ -807,7 +811,10 @@ struct PairCfg {
 #endif
   // float64 16-lane groups with their 15 rounds unrolled: m=32 (128 registers of state) needs the whole file
   // (1261 spilled VGPRs at two waves per SIMD), m=24 (96) fits two waves
-  static constexpr int F64_TWO_WAVE_XREGS = G_ >= 16 ? 100 : 140;
+#ifndef SQFA_F64_TWO_WAVE_XREGS
+#define SQFA_F64_TWO_WAVE_XREGS 140
+#endif
+  static constexpr int F64_TWO_WAVE_XREGS = G_ >= 16 ? 100 : SQFA_F64_TWO_WAVE_XREGS;
   static constexpr int MIN_WAVES = sizeof(T) == 8 ? (XREGS <= 64 ? SQFA_F64_SMALL_WAVES : (XREGS <= F64_TWO_WAVE_XREGS ? 2 : 1))
                                                   : (XREGS <= 64 ? 4 : (XREGS <= 100 ? 3 : (XREGS <= 170 ? 2 : 1)));
   // L_j^-1 staged in LDS as a packed lower triangle (one-wave workgroups, m >= 32: 8 instead of 7
@@ -825,6 +832,12 @@ struct PairCfg {
 #endif
   static constexpr int FACTOR_SWEEPS = SQFA_FACTOR_SWEEPS >= 0 ? SQFA_FACTOR_SWEEPS : (MR_ >= SQFA_FACTOR_MIN_M ? 2 : 0);
   static constexpr bool DENSE_FACTOR = FACTOR_SWEEPS > 0;
+  // the pass orthogonalises the columns in the metric of the mean class (class_factor_mean_kernel) for the sizes whose stacked
+  // columns (2 MR rows of double state per slot) fit the register file of a lone wave
+#ifndef SQFA_FACTOR_MEAN
+#define SQFA_FACTOR_MEAN 1
+#endif
+  static constexpr bool MEAN_METRIC = SQFA_FACTOR_MEAN && DENSE_FACTOR && MR_ <= 33;
   // The pass is a handful of lone waves: its duration is one wave's latency whatever the class count (float32: 10 us at
   // m <= 16, 20 at 17, 32-37 at 20-24, 45 / 76 at 32 / 33, 0.28 / 0.40 ms at 48 / 64), while what it saves is a share of the
   // pair kernel (m=16 8 %, 17 6 %, 20-24 3 %, 32-64 9-10 %; m=12 2 %).  Launches with fewer pairs (per shard) than this
@@ -1268,6 +1281,82 @@ struct FactorCfg {
   static constexpr int PPW = 64 / G;
 };
 
+// At most `max_sweeps` sweeps of the pair kernel's own rotations over the columns a lane group holds (slot c of lane g is
+// column c*G + g); stops after the first sweep whose rotations all stay below Real<T>::early2.  Shared by the class factor
+// pass (two sweeps, need not converge) and the per-class eigen-decomposition (to convergence).
+// MR: the matrix size (decides which slots hold real columns and whether the last one is a lone column); ROWS: the rows a
+// column has here -- MR, or 2 MR for the stacked columns of the mean-metric factor pass.
+template <typename T, int MR, int G, int CPL, int ROWS = MR>
+__device__ __forceinline__ int class_jacobi_sweeps(T (&x)[CPL][ROWS], T (&D)[CPL], int max_sweeps) {
+  using R = Real<T>;
+  constexpr bool LONE = (MR == G * (CPL - 1) + 1);
+  const T tol2 = R::kEps * R::kEps * T(MR);
+  T nrm[CPL];
+  int sweeps = 0;
+  bool more = true;
+  while (more && sweeps < max_sweeps) {
+    {  // fold the scales back when one leaves the safe range (see the pair kernel's sweep loop): only a long run gets there
+      bool far = false;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) far = far || !(D[c] > R::kScaleLo && D[c] < R::kScaleHi);
+      if (__any(far)) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          const T dc = R::sqrt_(D[c]);
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) x[c][r] *= dc;
+          D[c] = T(1);
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      T a = T(0);
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) a = R::fma_(x[c][r], x[c][r], a);
+      nrm[c] = a * D[c];
+    }
+    bool big = false;
+    if constexpr (SQFA_LOCAL_TOURNAMENT && G == 1) {
+      local_rounds<T, ROWS, CPL, 1>(x, nrm, D, tol2, big);
+    } else {
+      constexpr int CE = z_visits_cfg<G, MR, CPL>() ? CPL - 1 : CPL;
+#pragma unroll
+      for (int c1 = 0; c1 < CE; ++c1) {
+#pragma unroll
+        for (int c2 = c1 + 1; c2 < CE; ++c2) {
+          const T gh = dot_cols<T, ROWS>(x[c1], x[c2]);
+          T u, ru, k, g2;
+          rot_scaled<T, ROWS>(nrm[c1], nrm[c2], gh, D[c1], D[c2], tol2, T(1), u, ru, k, g2, big);
+          const T kgh = k * gh, kg2 = k * g2;
+          const T a1 = -(kgh * D[c2]), a2 = kgh * D[c1];
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) {
+            const T xp = x[c1][r];
+            x[c1][r] = R::fma_(a1, x[c2][r], xp);
+            x[c2][r] = R::fma_(a2, xp, x[c2][r]);
+          }
+          D[c1] *= u;
+          D[c2] *= u;
+          nrm[c1] -= kg2;
+          nrm[c2] += kg2;
+        }
+      }
+    }
+    constexpr int STATIC_G = sizeof(T) == 4 ? 32 : 16;  // PairCfg::STATIC_G's rule for the arithmetic type used HERE
+    if constexpr (G > 1 && G <= STATIC_G) {
+      cross_rounds_static<T, ROWS, G, CPL, 1, LONE ? 1 : 0>(x, nrm, D, tol2, big);
+    } else if constexpr (G > STATIC_G) {
+#pragma unroll 1
+      for (int s = 1; s < G; ++s) cross_round<T, ROWS, CPL, 0, 0, LONE>(x, nrm, D, s, tol2, big);
+    }
+    if constexpr (z_visits_cfg<G, MR, CPL>()) z_visits<T, ROWS, G, CPL, swizzled_rows_of_8<T, G, MR>(), 0>(x, nrm, D, tol2, big);
+    more = __any(big);
+    ++sweeps;
+  }
+  return sweeps;
+}
+
 template <typename Cfg>
 __global__ __launch_bounds__(64) void class_factor_kernel(typename Cfg::io_type* __restrict__ LT, int nA, int max_sweeps) {
   using Tio = typename Cfg::io_type;
@@ -1291,58 +1380,10 @@ __global__ __launch_bounds__(64) void class_factor_kernel(typename Cfg::io_type*
 #pragma unroll
     for (int k = 0; k < MR; ++k) x[c][k] = real_col ? (T)src[k] : T(0);
   }
-  const T tol2 = R::kEps * R::kEps * T(MR);
-  T nrm[CPL], D[CPL];
+  T D[CPL];
 #pragma unroll
   for (int c = 0; c < CPL; ++c) D[c] = T(1);
-  int sweeps = 0;
-  bool more = true;
-  while (more && sweeps < max_sweeps) {
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-      T a = T(0);
-#pragma unroll
-      for (int r = 0; r < MR; ++r) a = R::fma_(x[c][r], x[c][r], a);
-      nrm[c] = a * D[c];
-    }
-    bool big = false;
-    if constexpr (SQFA_LOCAL_TOURNAMENT && G == 1) {
-      local_rounds<T, MR, CPL, 1>(x, nrm, D, tol2, big);
-    } else {
-      constexpr int CE = z_visits_cfg<G, MR, CPL>() ? CPL - 1 : CPL;
-#pragma unroll
-      for (int c1 = 0; c1 < CE; ++c1) {
-#pragma unroll
-        for (int c2 = c1 + 1; c2 < CE; ++c2) {
-          const T gh = dot_cols<T, MR>(x[c1], x[c2]);
-          T u, ru, k, g2;
-          rot_scaled<T, MR>(nrm[c1], nrm[c2], gh, D[c1], D[c2], tol2, T(1), u, ru, k, g2, big);
-          const T kgh = k * gh, kg2 = k * g2;
-          const T a1 = -(kgh * D[c2]), a2 = kgh * D[c1];
-#pragma unroll
-          for (int r = 0; r < MR; ++r) {
-            const T xp = x[c1][r];
-            x[c1][r] = R::fma_(a1, x[c2][r], xp);
-            x[c2][r] = R::fma_(a2, xp, x[c2][r]);
-          }
-          D[c1] *= u;
-          D[c2] *= u;
-          nrm[c1] -= kg2;
-          nrm[c2] += kg2;
-        }
-      }
-    }
-    constexpr int STATIC_G = sizeof(T) == 4 ? 32 : 16;  // PairCfg::STATIC_G's rule for the arithmetic type used HERE
-    if constexpr (G > 1 && G <= STATIC_G) {
-      cross_rounds_static<T, MR, G, CPL, 1>(x, nrm, D, tol2, big);
-    } else if constexpr (G > STATIC_G) {
-#pragma unroll 1
-      for (int s = 1; s < G; ++s) cross_round<T, MR, CPL, 0, 0, (MR == G * (CPL - 1) + 1)>(x, nrm, D, s, tol2, big);
-    }
-    if constexpr (z_visits_cfg<G, MR, CPL>()) z_visits<T, MR, G, CPL, swizzled_rows_of_8<T, G, MR>(), 0>(x, nrm, D, tol2, big);
-    more = __any(big);
-    ++sweeps;
-  }
+  class_jacobi_sweeps<T, MR, G, CPL>(x, D, max_sweeps);
   // (Writing the columns back sorted by norm was tried -- a numpy emulation with a round-robin tournament gained most of a
   // sweep on unrelated ill-conditioned pencils -- and changes nothing under this kernel's pairing order: cond 1e3, m=16 / 32,
   // 6.54 / 7.35 sweeps unsorted, 6.67 / 7.46 ascending, 6.57 / 7.43 descending.  Columns stay where they are.)
@@ -1360,6 +1401,129 @@ __global__ __launch_bounds__(64) void class_factor_kernel(typename Cfg::io_type*
   }
 }
 
+// ---- K0b in the metric of the MEAN class (round 4) ---------------------------------------------------------------------
+// K1's sweeps start from the Gram matrix F_i^T Sigma_j^-1 F_i.  Orthogonal columns of F_i (the pass above) make it diagonal
+// when Sigma_j is a multiple of I -- the best class-level choice for classes that scatter around one, and no help at all for
+// classes that share a dominant covariance, Sigma_c = Sbar^1/2 (I + E_c) Sbar^1/2 (real class statistics do): there the
+// class-level choice is F_i^T Sbar^-1 F_i diagonal, i.e. the columns of  W_i = Lbar^-1 F_i  orthogonal (Sbar = Lbar Lbar^T
+// the mean of the classes).  Emulated (tools/mean_metric_probe.py, sweeps per wave): shared structure 5.8-6.7 -> 5.0-6.1,
+// BASELINE generator 5.2 / 5.5 / 6.0 -> 5.1 / 5.1 / 6.0 (m = 16 / 17 / 32).
+// The sweeps run on STACKED columns [W; eps L] (2 MR rows): the inner products are those of W up to eps^2 |L|^2 (eps = 2^-30:
+// ~1e-18 relative -- these sweeps need not even converge), and the rows of L ride along, so that what is written back is
+// L_i V with V EXACTLY the product of the plane rotations applied: (L_i V)(L_i V)^T = Sigma_i to rounding whatever the
+// condition of Sbar (two triangular products Lbar (Lbar^-1 L_i V) would lose cond(Lbar) digits).  Double arithmetic.
+// mean_linv: Lbar^-1, MR x MR row-major, identity padded (written by the mean block of the Cholesky prologue).
+template <typename Cfg>
+__global__ __launch_bounds__(64) void class_factor_mean_kernel(typename Cfg::io_type* __restrict__ LT, int nA, int max_sweeps,
+                                                               const double* __restrict__ mean_linv) {
+  using Tio = typename Cfg::io_type;
+  using T = double;
+  using R = Real<T>;
+  constexpr int MR = Cfg::MR, G = Cfg::G, CPL = Cfg::CPL, PPW = Cfg::PPW, ROWS = 2 * MR;
+  constexpr T kStack = T(1.0 / (1 << 30)), kUnstack = T(1 << 30);
+  __shared__ T s_li[MR * MR];
+  const int lane = threadIdx.x & 63;
+  for (int k = lane; k < MR * MR; k += 64) s_li[k] = mean_linv[k];
+  __syncthreads();
+  const int g = lane % G;
+  const int cls = blockIdx.x * PPW + lane / G;
+  Tio* lt = LT + (size_t)(cls < nA ? cls : nA - 1) * (MR * MR);
+  T x[CPL][ROWS];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int col = c * G + g;
+    const Tio* src = lt + (size_t)(col < MR ? col : 0) * MR;
+    const bool real_col = col < MR;
+#pragma unroll
+    for (int k = 0; k < MR; ++k) x[c][MR + k] = real_col ? (T)src[k] : T(0);
+    // W = Lbar^-1 l  (lower triangular)
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+      T acc = T(0);
+#pragma unroll
+      for (int k = 0; k <= r; ++k) acc = R::fma_(s_li[r * MR + k], x[c][MR + k], acc);
+      x[c][r] = acc;
+    }
+#pragma unroll
+    for (int k = 0; k < MR; ++k) x[c][MR + k] *= kStack;
+  }
+  T D[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) D[c] = T(1);
+  class_jacobi_sweeps<T, MR, G, CPL, ROWS>(x, D, max_sweeps);
+  if (cls < nA) {
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const int col = c * G + g;
+      if (col < MR) {
+        const T dc = R::sqrt_(D[c]) * kUnstack;
+        Tio* dst = lt + (size_t)col * MR;
+#pragma unroll
+        for (int r = 0; r < MR; ++r) dst[r] = (Tio)(x[c][MR + r] * dc);
+      }
+    }
+  }
+}
+
+// ---- per-class symmetric eigen-decomposition (spd_log / spd_sqrt of the reference, src/sqfa/linalg.py:121-141,165-183) ----
+// The same lane-group Jacobi run to CONVERGENCE on the Cholesky factor of each class: L V = Q Sigma (columns orthogonal),
+// so S = L L^T = Q Sigma^2 Q^T -- eigenvalues lambda_k = |y_k|^2 with the RELATIVE accuracy of one-sided Jacobi on a
+// factor (what log needs), eigenvectors q_k = y_k / |y_k|.  Always double arithmetic; U (n,m,m) row-major with the
+// eigenvectors as COLUMNS and lam (n,m), both double, unsorted.  LT: the (identity-padded, column-contiguous) factors
+// written by the Cholesky prologue, read only.
+template <typename Cfg>
+__global__ __launch_bounds__(64) void class_eig_kernel(const typename Cfg::io_type* __restrict__ LT, int n, int m,
+                                                       double* __restrict__ U, double* __restrict__ lam) {
+  using Tio = typename Cfg::io_type;
+  using T = double;
+  using R = Real<T>;
+  constexpr int MR = Cfg::MR, G = Cfg::G, CPL = Cfg::CPL, PPW = Cfg::PPW;
+  const int lane = threadIdx.x & 63;
+  const int g = lane % G;
+  const int cls = blockIdx.x * PPW + lane / G;
+  const Tio* lt = LT + (size_t)(cls < n ? cls : n - 1) * (MR * MR);
+  T x[CPL][MR];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int col = c * G + g;
+    const Tio* src = lt + (size_t)(col < MR ? col : 0) * MR;
+    const bool real_col = col < MR;
+#pragma unroll
+    for (int k = 0; k < MR; ++k) x[c][k] = real_col ? (T)src[k] : T(0);
+  }
+  T D[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) D[c] = T(1);
+  class_jacobi_sweeps<T, MR, G, CPL>(x, D, 40);
+  if (cls < n) {
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const int col = c * G + g;
+      if (col < m) {   // identity-padded columns (col >= m) never mix with the real ones: their inner products are exactly 0
+        T a = T(0);
+#pragma unroll
+        for (int r = 0; r < MR; ++r) a = R::fma_(x[c][r], x[c][r], a);
+        const T l = a * D[c];
+        lam[(size_t)cls * m + col] = l;
+        const T inv = R::sqrt_(D[c]) / R::sqrt_(l);   // NaN for a class that is not positive definite: surfaces downstream
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+          if (r < m) U[((size_t)cls * m + r) * m + col] = x[c][r] * inv;
+        }
+      }
+    }
+  }
+}
+
+template <typename Cfg>
+hipError_t launch_class_eig(const void* LT, int n, int m, double* U, double* lam, hipStream_t stream) {
+  using T = typename Cfg::type;
+  using FC = FactorCfg<T, Cfg::MR>;
+  const int blocks = (n + FC::PPW - 1) / FC::PPW;
+  hipLaunchKernelGGL((class_eig_kernel<FC>), dim3(blocks), dim3(64), 0, stream, static_cast<const T*>(LT), n, m, U, lam);
+  return hipGetLastError();
+}
+
 template <typename Cfg>
 hipError_t launch_class_factors(const PairParams& p, hipStream_t stream) {
   if constexpr (!Cfg::DENSE_FACTOR) {
@@ -1370,6 +1534,13 @@ hipError_t launch_class_factors(const PairParams& p, hipStream_t stream) {
     const long pairs = p.self_mode ? (long)p.nA * (p.nA - 1) / 2 : (long)p.nA * p.nB;
     if (p.factor_mode < 0 || (p.factor_mode == 0 && pairs / p.shard_count < Cfg::FACTOR_MIN_PAIRS)) return hipSuccess;  // same decision on every shard of a job
     const int blocks = (p.nA + FC::PPW - 1) / FC::PPW;
+    if constexpr (Cfg::MEAN_METRIC) {
+      if (p.mean_linv != nullptr) {
+        hipLaunchKernelGGL((class_factor_mean_kernel<FC>), dim3(blocks), dim3(64), 0, stream,
+                           static_cast<T*>(const_cast<void*>(p.LT)), p.nA, Cfg::FACTOR_SWEEPS, p.mean_linv);
+        return hipGetLastError();
+      }
+    }
     hipLaunchKernelGGL((class_factor_kernel<FC>), dim3(blocks), dim3(64), 0, stream,
                        static_cast<T*>(const_cast<void*>(p.LT)), p.nA, Cfg::FACTOR_SWEEPS);
     return hipGetLastError();

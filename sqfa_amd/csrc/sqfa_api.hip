@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -11,29 +12,38 @@
 #include "../../include/sqfa_hip.h"
 #include "configs.hpp"
 #include "pair_kernel.hpp"
+#include "pair_kernel_2d.hpp"
 
 namespace sqfa {
 
 // ---- per-configuration launchers (defined in pair_inst.hip translation units) -----------
 #define SQFA_DECL_F32(T, MR, G, CPL, TJ, WV) \
   hipError_t launch_pair_f32_##MR(const PairParams&, hipStream_t);   \
-  hipError_t launch_factor_f32_##MR(const PairParams&, hipStream_t);
+  hipError_t launch_factor_f32_##MR(const PairParams&, hipStream_t); \
+  hipError_t launch_classeig_f32_##MR(const void*, int, int, double*, double*, hipStream_t);
 #define SQFA_DECL_F64(T, MR, G, CPL, TJ, WV) \
   hipError_t launch_pair_f64_##MR(const PairParams&, hipStream_t);   \
-  hipError_t launch_factor_f64_##MR(const PairParams&, hipStream_t);
+  hipError_t launch_factor_f64_##MR(const PairParams&, hipStream_t); \
+  hipError_t launch_classeig_f64_##MR(const void*, int, int, double*, double*, hipStream_t);
 SQFA_CONFIGS_F32(SQFA_DECL_F32)
 SQFA_CONFIGS_F64(SQFA_DECL_F64)
 #define SQFA_DECL_F32S(T, MR, G, CPL, TJ, WV) \
   hipError_t launch_pair_f32s_##MR(const PairParams&, hipStream_t);  \
   hipError_t launch_factor_f32s_##MR(const PairParams&, hipStream_t);
 SQFA_CONFIGS_F32_SMALL(SQFA_DECL_F32S)
+#define SQFA_DECL_F64S(T, MR, G, CPL, TJ, WV) \
+  hipError_t launch_pair_f64s_##MR(const PairParams&, hipStream_t);  \
+  hipError_t launch_factor_f64s_##MR(const PairParams&, hipStream_t);
+SQFA_CONFIGS_F64_SMALL(SQFA_DECL_F64S)
 
 #define SQFA_DECL2D_F32(T, MR, GC, CPL, TJ, WV, RS) \
   hipError_t launch_pair2d_f32_##MR(const PairParams&, hipStream_t); \
-  hipError_t launch_factor2d_f32_##MR(const PairParams&, hipStream_t);
+  hipError_t launch_factor2d_f32_##MR(const PairParams&, hipStream_t); \
+  hipError_t launch_classeig2d_f32_##MR(const void*, int, int, double*, double*, hipStream_t);
 #define SQFA_DECL2D_F64(T, MR, GC, CPL, TJ, WV, RS) \
   hipError_t launch_pair2d_f64_##MR(const PairParams&, hipStream_t); \
-  hipError_t launch_factor2d_f64_##MR(const PairParams&, hipStream_t);
+  hipError_t launch_factor2d_f64_##MR(const PairParams&, hipStream_t); \
+  hipError_t launch_classeig2d_f64_##MR(const void*, int, int, double*, double*, hipStream_t);
 SQFA_CONFIGS2D_F32(SQFA_DECL2D_F32)
 SQFA_CONFIGS2D_F64(SQFA_DECL2D_F64)
 
@@ -41,14 +51,17 @@ struct Geometry {
   int MR, G, CPL, TJ, TI, WV;  // TJ: widest tile (B classes); a launch may use TJ/2, TJ/4 ... >= WV
   hipError_t (*launch)(const PairParams&, hipStream_t);
   hipError_t (*factor)(const PairParams&, hipStream_t);  // K0b, the class factor pass
+  hipError_t (*eig)(const void*, int, int, double*, double*, hipStream_t) = nullptr;  // per-class eigen-decomposition (regular rows)
+  bool mean_metric = false;     // the row's factor pass runs in the metric of the mean class (Cfg::MEAN_METRIC)
+  long factor_min_pairs = 0;    // Cfg::FACTOR_MIN_PAIRS: launches with fewer pairs per shard skip the factor pass
 };
 
 // The geometry table: every whole-column row (pair_kernel.hpp) and every 2-D row (pair_kernel_2d.hpp: GC column lanes x 2
 // row lanes per pair, G = 2 GC lanes per pair) of configs.hpp; a problem of size m runs on the smallest MR >= m.  A launch
 // with few pairs (`pairs` = pairs per shard; < 0: not known, regular rows only) takes the small-launch row of that MR if
-// there is one (configs.hpp, SQFA_CONFIGS_F32_SMALL).  g_geometry_mode: sqfa_airm_geometry_policy.
-static int g_geometry_mode = 0;
-static bool find_geometry(int m, int dtype, long pairs, Geometry* out) {
+// there is one (configs.hpp, SQFA_CONFIGS_F32_SMALL).  geometry_mode: sqfa_airm_options::geometry_policy of the call (0 by
+// pair count, 1 small-launch rows wherever one exists, -1 never) -- a per-call argument, no process-wide state.
+static bool find_geometry(int m, int dtype, long pairs, Geometry* out, int geometry_mode = 0) {
   bool found = false;
   Geometry best{};
   auto consider = [&](int dt, const Geometry& g) {
@@ -57,22 +70,26 @@ static bool find_geometry(int m, int dtype, long pairs, Geometry* out) {
       found = true;
     }
   };
-#define SQFA_ROW_F32(T, MR_, G_, CPL_, TJ_, WV_) consider(SQFA_F32, Geometry{MR_, G_, CPL_, TJ_, 64 / G_, WV_, launch_pair_f32_##MR_, launch_factor_f32_##MR_});
-#define SQFA_ROW_F64(T, MR_, G_, CPL_, TJ_, WV_) consider(SQFA_F64, Geometry{MR_, G_, CPL_, TJ_, 64 / G_, WV_, launch_pair_f64_##MR_, launch_factor_f64_##MR_});
+#define SQFA_ROW_F32(T, MR_, G_, CPL_, TJ_, WV_) consider(SQFA_F32, Geometry{MR_, G_, CPL_, TJ_, 64 / G_, WV_, launch_pair_f32_##MR_, launch_factor_f32_##MR_, launch_classeig_f32_##MR_, PairCfg<float, MR_, G_, CPL_, TJ_, WV_>::MEAN_METRIC, PairCfg<float, MR_, G_, CPL_, TJ_, WV_>::FACTOR_MIN_PAIRS});
+#define SQFA_ROW_F64(T, MR_, G_, CPL_, TJ_, WV_) consider(SQFA_F64, Geometry{MR_, G_, CPL_, TJ_, 64 / G_, WV_, launch_pair_f64_##MR_, launch_factor_f64_##MR_, launch_classeig_f64_##MR_, PairCfg<double, MR_, G_, CPL_, TJ_, WV_>::MEAN_METRIC, PairCfg<double, MR_, G_, CPL_, TJ_, WV_>::FACTOR_MIN_PAIRS});
 #define SQFA_ROW2D_F32(T, MR_, GC_, CPL_, TJ_, WV_, RS_) \
-  consider(SQFA_F32, Geometry{MR_, 2 * GC_, CPL_, TJ_, 64 / (2 * GC_), WV_, launch_pair2d_f32_##MR_, launch_factor2d_f32_##MR_});
+  consider(SQFA_F32, Geometry{MR_, 2 * GC_, CPL_, TJ_, 64 / (2 * GC_), WV_, launch_pair2d_f32_##MR_, launch_factor2d_f32_##MR_, launch_classeig2d_f32_##MR_, PairCfg2D<float, MR_, GC_, CPL_, TJ_, WV_, RS_>::MEAN_METRIC, PairCfg2D<float, MR_, GC_, CPL_, TJ_, WV_, RS_>::FACTOR_MIN_PAIRS});
 #define SQFA_ROW2D_F64(T, MR_, GC_, CPL_, TJ_, WV_, RS_) \
-  consider(SQFA_F64, Geometry{MR_, 2 * GC_, CPL_, TJ_, 64 / (2 * GC_), WV_, launch_pair2d_f64_##MR_, launch_factor2d_f64_##MR_});
+  consider(SQFA_F64, Geometry{MR_, 2 * GC_, CPL_, TJ_, 64 / (2 * GC_), WV_, launch_pair2d_f64_##MR_, launch_factor2d_f64_##MR_, launch_classeig2d_f64_##MR_, PairCfg2D<double, MR_, GC_, CPL_, TJ_, WV_, RS_>::MEAN_METRIC, PairCfg2D<double, MR_, GC_, CPL_, TJ_, WV_, RS_>::FACTOR_MIN_PAIRS});
   SQFA_CONFIGS_F32(SQFA_ROW_F32)
   SQFA_CONFIGS_F64(SQFA_ROW_F64)
   SQFA_CONFIGS2D_F32(SQFA_ROW2D_F32)
   SQFA_CONFIGS2D_F64(SQFA_ROW2D_F64)
-  if (found && g_geometry_mode >= 0 && pairs >= 0) {
+  if (found && geometry_mode >= 0 && pairs >= 0) {
     // same padded size, more lanes per pair
 #define SQFA_ROW_F32S(T, MR_, G_, CPL_, TJ_, WV_)                                                                        \
-    if (dtype == SQFA_F32 && best.MR == MR_ && (g_geometry_mode > 0 || pairs < small_launch_max_pairs(MR_)))                \
-      best = Geometry{MR_, G_, CPL_, TJ_, 64 / G_, WV_, launch_pair_f32s_##MR_, launch_factor_f32s_##MR_};
+    if (dtype == SQFA_F32 && best.MR == MR_ && (geometry_mode > 0 || pairs < small_launch_max_pairs(MR_)))                \
+      best = Geometry{MR_, G_, CPL_, TJ_, 64 / G_, WV_, launch_pair_f32s_##MR_, launch_factor_f32s_##MR_, best.eig, PairCfg<float, MR_, G_, CPL_, TJ_, WV_>::MEAN_METRIC, PairCfg<float, MR_, G_, CPL_, TJ_, WV_>::FACTOR_MIN_PAIRS};
     SQFA_CONFIGS_F32_SMALL(SQFA_ROW_F32S)
+#define SQFA_ROW_F64S(T, MR_, G_, CPL_, TJ_, WV_)                                                                        \
+    if (dtype == SQFA_F64 && best.MR == MR_ && (geometry_mode > 0 || pairs < small_launch_max_pairs_f64(MR_)))              \
+      best = Geometry{MR_, G_, CPL_, TJ_, 64 / G_, WV_, launch_pair_f64s_##MR_, launch_factor_f64s_##MR_, best.eig, PairCfg<double, MR_, G_, CPL_, TJ_, WV_>::MEAN_METRIC, PairCfg<double, MR_, G_, CPL_, TJ_, WV_>::FACTOR_MIN_PAIRS};
+    SQFA_CONFIGS_F64_SMALL(SQFA_ROW_F64S)
   }
   if (found) *out = best;
   return found;
@@ -92,17 +109,15 @@ static int max_dim() {
 }
 
 static thread_local char g_last_error[256] = "";
-static unsigned long long* g_sweep_counter = nullptr;
-static int g_factor_mode = 0;  // sqfa_airm_class_factor_policy
 
 // optional per-launch timing of the pair tile kernel with HIP events on the caller's stream
 struct EventPair { hipEvent_t a, b; };
-static bool g_profile = false;
+static std::atomic<bool> g_profile{false};
 static std::vector<EventPair> g_events;
 static std::mutex g_events_mutex;  // the event lists are shared by every host thread that calls into the library
 }  // namespace sqfa
 // shared with project_kernel.hip
-bool sqfa_profile_enabled() { return sqfa::g_profile; }
+bool sqfa_profile_enabled() { return sqfa::g_profile.load(); }
 std::vector<std::pair<hipEvent_t, hipEvent_t>>& sqfa_project_events() {
   static std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   return ev;
@@ -116,8 +131,9 @@ namespace sqfa {
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct WorkspaceLayout {
-  size_t off_lt, off_linv, off_slab, off_loss, off_flag, off_rows, total;
+  size_t off_lt, off_linv, off_slab, off_loss, off_flag, off_rows, off_mean, total;
 };
+constexpr int kMeanParts = 32;   // class groups of the mean-class partial sums (mean_partial_kernel)
 
 // Tiles of a shard for tile width tj (same enumeration as the kernel's compact grid).
 static long shard_tiles(int nA, int nBeff, const Geometry& g, int tj, int self_mode, int shard_index, int shard_count) {
@@ -198,6 +214,8 @@ static WorkspaceLayout layout(int nA, int nBeff, const Geometry& g, size_t esz, 
   w.off_loss = o; o = align_up(o + tiles * esz);
   w.off_flag = o; o = align_up(o + tiles * 2 * sizeof(int));
   w.off_rows = o; o = align_up(o + (nbi + 1) * sizeof(int));
+  // mean-metric factor pass: kMeanParts partial sums of the A classes (MR x MR doubles each), then Lbar^-1 (MR x MR doubles)
+  w.off_mean = o; o = align_up(o + (size_t)(kMeanParts + 1) * g.MR * g.MR * sizeof(double));
   w.total = o;
   return w;
 }
@@ -220,10 +238,31 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
   return y;
 }
 
+// Partial sums of the class matrices for the mean class of the mean-metric factor pass: block b adds the classes b, b + P,
+// b + 2P, ... (P = gridDim.x) entry by entry in that order -- fixed association, bitwise reproducible.  out[b][m*m] doubles.
+template <typename T>
+__global__ __launch_bounds__(256) void mean_partial_kernel(const T* __restrict__ S, int n, int m, double* __restrict__ out) {
+  const int b = blockIdx.x, P = gridDim.x;
+  for (int e = threadIdx.x; e < m * m; e += 256) {
+    double a0 = 0.0, a1 = 0.0;
+    int c = b;
+    for (; c + P < n; c += 2 * P) {
+      a0 += (double)S[(size_t)c * m * m + e];
+      a1 += (double)S[(size_t)(c + P) * m * m + e];
+    }
+    if (c < n) a0 += (double)S[(size_t)c * m * m + e];
+    out[(size_t)b * m * m + e] = a0 + a1;
+  }
+}
+
+// mean_parts != nullptr: ONE extra block (blockIdx.x == n_classes) factorises the mean of the classes (the sum of the
+// n_parts partial sums / n_classes) and writes Lbar^-1 as MR x MR row-major doubles, identity padded, to mean_linv.
 template <typename T, int MAXM>
 __global__ __launch_bounds__(256) void cholesky_kernel(const T* __restrict__ S, int m, int MR,
                                                        T* __restrict__ LT, T* __restrict__ Linv,
-                                                       int* __restrict__ row_start, PairParams pp, int TI) {
+                                                       int* __restrict__ row_start, PairParams pp, int TI,
+                                                       int n_classes = 0, const double* __restrict__ mean_parts = nullptr,
+                                                       int n_parts = 0, double* __restrict__ mean_linv = nullptr) {
   if (row_start != nullptr && blockIdx.x == 0) {
     // slab slot table for K2: owned tiles before each block-row, in the compact grid's order.  The per-row
     // counts (integer divisions) are evaluated by 256 threads at once, thread 0 only adds them up: a serial
@@ -257,10 +296,21 @@ __global__ __launch_bounds__(256) void cholesky_kernel(const T* __restrict__ S, 
   __shared__ double b[MAXM][MAXM + 1];
   __shared__ double rd[MAXM];  // 1 / L[k][k]
   const int c = blockIdx.x, t = threadIdx.x;
-  const T* s = S + (size_t)c * m * m;
-  for (int idx = t; idx < m * m; idx += 256) {
-    a[idx / m][idx % m] = (double)s[idx];
-    b[idx / m][idx % m] = 0.0;
+  const bool mean_block = mean_parts != nullptr && c == n_classes;
+  if (mean_block) {
+    const double inv_n = 1.0 / (double)n_classes;
+    for (int idx = t; idx < m * m; idx += 256) {
+      double acc = 0.0;
+      for (int q = 0; q < n_parts; ++q) acc += mean_parts[(size_t)q * m * m + idx];
+      a[idx / m][idx % m] = acc * inv_n;
+      b[idx / m][idx % m] = 0.0;
+    }
+  } else {
+    const T* s = S + (size_t)c * m * m;
+    for (int idx = t; idx < m * m; idx += 256) {
+      a[idx / m][idx % m] = (double)s[idx];
+      b[idx / m][idx % m] = 0.0;
+    }
   }
   __syncthreads();
 #ifndef SQFA_CHOL_ONE_BARRIER
@@ -326,6 +376,13 @@ __global__ __launch_bounds__(256) void cholesky_kernel(const T* __restrict__ S, 
     }
   }
   __syncthreads();
+  if (mean_block) {
+    for (int idx = t; idx < MR * MR; idx += 256) {
+      const int r = idx / MR, k = idx % MR;
+      mean_linv[idx] = (r < m && k < m) ? (k <= r ? b[r][k] : 0.0) : (r == k ? 1.0 : 0.0);
+    }
+    return;
+  }
   const size_t base = (size_t)c * MR * MR;
   for (int idx = t; idx < MR * MR; idx += 256) {
     const int r = idx / MR, k = idx % MR;
@@ -506,6 +563,94 @@ __global__ __launch_bounds__(SQFA_K2_THREADS) void finalize_kernel(const PairPar
   }
 }
 
+// ---- per-class matrix functions f(S) = Q f(Lambda) Q^T and their backward -----------------------------------------------
+// (spd_log / spd_sqrt of the reference, src/sqfa/linalg.py:121-141, 165-183: torch.linalg.eigh + einsum there.)
+// One 256-thread workgroup per class; Q (m x m, eigenvectors as columns) and the small intermediates live in LDS as
+// double whatever the problem's type; m <= 64.
+__device__ __forceinline__ double spd_fn(int kind, double l) {
+  return kind == SQFA_SPD_LOG ? log(l) : (kind == SQFA_SPD_SQRT ? sqrt(l) : 1.0 / sqrt(l));
+}
+// divided difference (f(a) - f(b)) / (a - b), f'(a) on the diagonal -- in forms that stay accurate when a ~ b
+// (torch's eigh backward divides by a - b: inf / NaN for repeated eigenvalues; this is its limit)
+__device__ __forceinline__ double spd_fn_dd(int kind, double a, double b) {
+  if (kind == SQFA_SPD_SQRT) return 1.0 / (sqrt(a) + sqrt(b));
+  if (kind == SQFA_SPD_INV_SQRT) {
+    const double ra = sqrt(a), rb = sqrt(b);
+    return -1.0 / (ra * rb * (ra + rb));
+  }
+  const double r = (a - b) / b;                     // log: log1p(r) / (r b)
+  if (fabs(r) < 1e-8) return (1.0 - 0.5 * r) / b;
+  return log1p(r) / (r * b);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void spd_function_kernel(const double* __restrict__ U, const double* __restrict__ lam, int m,
+                                                           int kind, T* __restrict__ F) {
+  extern __shared__ double sh[];   // q[m][m], f[m]
+  double* q = sh;
+  double* f = sh + m * m;
+  const int c = blockIdx.x, t = threadIdx.x;
+  for (int k = t; k < m * m; k += 256) q[k] = U[(size_t)c * m * m + k];
+  for (int k = t; k < m; k += 256) f[k] = spd_fn(kind, lam[(size_t)c * m + k]);
+  __syncthreads();
+  for (int e = t; e < m * m; e += 256) {
+    const int r = e / m, cc = e % m;
+    if (cc > r) continue;
+    double acc = 0.0;
+    for (int k = 0; k < m; ++k) acc += f[k] * q[r * m + k] * q[cc * m + k];
+    F[(size_t)c * m * m + r * m + cc] = (T)acc;
+    F[(size_t)c * m * m + cc * m + r] = (T)acc;   // exactly symmetric
+  }
+}
+
+// gradS = Q [ (Q^T sym(G) Q) o Gamma ] Q^T,  Gamma_kl = divided difference of f at (lambda_k, lambda_l)  (Daleckii-Krein)
+template <typename T>
+__global__ __launch_bounds__(256) void spd_function_backward_kernel(const double* __restrict__ U, const double* __restrict__ lam,
+                                                                    const T* __restrict__ G, int m, int kind, T* __restrict__ gradS) {
+  extern __shared__ double sh[];   // q[m][m], a[m][m], b[m][m], l[m]
+  double* q = sh;
+  double* a = sh + m * m;
+  double* b = sh + 2 * m * m;
+  double* l = sh + 3 * m * m;
+  const int c = blockIdx.x, t = threadIdx.x;
+  for (int k = t; k < m * m; k += 256) q[k] = U[(size_t)c * m * m + k];
+  for (int k = t; k < m; k += 256) l[k] = lam[(size_t)c * m + k];
+  for (int e = t; e < m * m; e += 256) {
+    const int r = e / m, cc = e % m;
+    a[e] = 0.5 * ((double)G[(size_t)c * m * m + r * m + cc] + (double)G[(size_t)c * m * m + cc * m + r]);
+  }
+  __syncthreads();
+  for (int e = t; e < m * m; e += 256) {           // b = sym(G) Q
+    const int r = e / m, k = e % m;
+    double acc = 0.0;
+    for (int j = 0; j < m; ++j) acc += a[r * m + j] * q[j * m + k];
+    b[e] = acc;
+  }
+  __syncthreads();
+  for (int e = t; e < m * m; e += 256) {           // a = (Q^T b) o Gamma
+    const int k = e / m, k2 = e % m;
+    double acc = 0.0;
+    for (int j = 0; j < m; ++j) acc += q[j * m + k] * b[j * m + k2];
+    a[e] = acc * spd_fn_dd(kind, l[k], l[k2]);
+  }
+  __syncthreads();
+  for (int e = t; e < m * m; e += 256) {           // b = Q a
+    const int r = e / m, k2 = e % m;
+    double acc = 0.0;
+    for (int k = 0; k < m; ++k) acc += q[r * m + k] * a[k * m + k2];
+    b[e] = acc;
+  }
+  __syncthreads();
+  for (int e = t; e < m * m; e += 256) {           // gradS = b Q^T  (lower triangle, mirrored: exactly symmetric)
+    const int r = e / m, cc = e % m;
+    if (cc > r) continue;
+    double acc = 0.0;
+    for (int k2 = 0; k2 < m; ++k2) acc += b[r * m + k2] * q[cc * m + k2];
+    gradS[(size_t)c * m * m + r * m + cc] = (T)acc;
+    gradS[(size_t)c * m * m + cc * m + r] = (T)acc;
+  }
+}
+
 static int fail(int code, const char* what, hipError_t e) {
   snprintf(g_last_error, sizeof(g_last_error), "%s: %s", what, e == hipSuccess ? "" : hipGetErrorString(e));
   return code;
@@ -522,25 +667,8 @@ const char* sqfa_hip_arch(void) { return "gfx950"; }
 int sqfa_hip_max_dim(void) { return max_dim(); }
 const char* sqfa_hip_last_error(void) { return g_last_error; }
 
-int sqfa_airm_set_sweep_counter(unsigned long long* device_counter2) {
-  g_sweep_counter = device_counter2;
-  return SQFA_OK;
-}
-
-int sqfa_airm_class_factor_policy(int mode) {
-  const int previous = g_factor_mode;
-  g_factor_mode = mode > 0 ? 1 : (mode < 0 ? -1 : 0);
-  return previous;
-}
-
-int sqfa_airm_geometry_policy(int mode) {
-  const int previous = g_geometry_mode;
-  g_geometry_mode = mode > 0 ? 1 : (mode < 0 ? -1 : 0);
-  return previous;
-}
-
 int sqfa_airm_profile(int enable) {
-  g_profile = enable != 0;
+  g_profile.store(enable != 0);
   return SQFA_OK;
 }
 
@@ -602,9 +730,9 @@ size_t sqfa_airm_workspace_bytes(int nA, int nB, int m, int dtype) {
   const int nBeff = nB == 0 ? nA : nB;
   // enough for any shard count: the regular row's and the small-launch row's layouts both fit
   Geometry g;
-  find_geometry(m, dtype, -1, &g);
+  find_geometry(m, dtype, -1, &g, -1);   // the regular row ...
   size_t need = layout(nA, nBeff, g, dtype == SQFA_F32 ? 4 : 8, nB == 0 ? 1 : 0).total;
-  find_geometry(m, dtype, 0, &g);
+  find_geometry(m, dtype, 0, &g, 1);     // ... and the small-launch row of the size, whatever policy a call will carry
   need = std::max(need, layout(nA, nBeff, g, dtype == SQFA_F32 ? 4 : 8, nB == 0 ? 1 : 0).total);
   return need;
 }
@@ -613,8 +741,13 @@ static int pairwise_impl(const void* A, int nA, const void* B, int nB, int m, in
                          double eps, int sqrt_mode, const void* pair_weights, double uniform_weight,
                          int shard_index, int shard_count, void* loss_out, void* gradA_out,
                          void* gradB_out, void* dist_out, void* eig_out, int* nonfinite_out,
-                         void* workspace, size_t workspace_bytes, void* stream_, const void* eig_weights) {
+                         void* workspace, size_t workspace_bytes, void* stream_, const void* eig_weights,
+                         const sqfa_airm_options* options) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  auto clamp = [](int v) { return v > 0 ? 1 : (v < 0 ? -1 : 0); };
+  const int geometry_mode = options ? clamp(options->geometry_policy) : 0;
+  const int factor_mode = options ? clamp(options->class_factor_policy) : 0;
+  const int mean_mode = options ? clamp(options->mean_metric_policy) : 0;
   g_last_error[0] = 0;
   if (A == nullptr || nA < 1 || m < 1 || nB < 0 || workspace == nullptr) return fail(SQFA_ERR_BAD_ARGUMENT, "null/size argument", hipSuccess);
   if (dtype != SQFA_F32 && dtype != SQFA_F64) return fail(SQFA_ERR_BAD_ARGUMENT, "dtype", hipSuccess);
@@ -623,7 +756,7 @@ static int pairwise_impl(const void* A, int nA, const void* B, int nB, int m, in
   const bool self_mode = (B == nullptr);
   if (self_mode && nA < 2) return fail(SQFA_ERR_BAD_ARGUMENT, "self mode needs at least two classes", hipSuccess);
   Geometry g;
-  if (!find_geometry(m, dtype, pair_count(nA, nB, shard_count), &g)) return fail(SQFA_ERR_UNSUPPORTED_M, "matrix size not supported", hipSuccess);
+  if (!find_geometry(m, dtype, pair_count(nA, nB, shard_count), &g, geometry_mode)) return fail(SQFA_ERR_UNSUPPORTED_M, "matrix size not supported", hipSuccess);
   const size_t esz = dtype == SQFA_F32 ? 4 : 8;
   const int nBeff = self_mode ? nA : nB;
   // tile width: halve while a shard's launch would leave workgroup slots empty.  Decided from
@@ -647,7 +780,7 @@ static int pairwise_impl(const void* A, int nA, const void* B, int nB, int m, in
   p.row_start = reinterpret_cast<int*>(ws + w.off_rows);
   p.dist_out = dist_out;
   p.eig_out = eig_out;
-  p.sweep_counter = g_sweep_counter;
+  p.sweep_counter = options ? options->sweep_counter : nullptr;
   p.nA = nA;
   p.nB = nBeff;
   p.m = m;
@@ -659,7 +792,7 @@ static int pairwise_impl(const void* A, int nA, const void* B, int nB, int m, in
   p.nbi = nbi;
   p.nbj = nbj;
   p.tj = tj;
-  p.factor_mode = g_factor_mode;
+  p.factor_mode = factor_mode;
   p.scale = scale;
   p.eps = eps;
   p.uniform_weight = uniform_weight;
@@ -668,6 +801,19 @@ static int pairwise_impl(const void* A, int nA, const void* B, int nB, int m, in
   p.uniform_weight_f = (float)uniform_weight;
 
   // K0: factors
+  // mean-metric factor pass (class_factor_mean_kernel): will K0b run, and on a size that has it?  Same rule as
+  // launch_class_factors (the decision depends on (nA, nB, shard count, options) only: every shard of a job decides alike).
+  const long pairs_per_shard = pair_count(nA, nB, shard_count);
+  const bool want_mean = g.mean_metric && mean_mode >= 0 && factor_mode >= 0 &&
+                         (factor_mode > 0 || pairs_per_shard >= g.factor_min_pairs) && nA >= 2;
+  double* mean_parts = reinterpret_cast<double*>(ws + w.off_mean);
+  double* mean_linv = mean_parts + (size_t)kMeanParts * g.MR * g.MR;
+  const int n_parts = nA < kMeanParts ? nA : kMeanParts;
+  if (want_mean) {
+    if (dtype == SQFA_F32) hipLaunchKernelGGL(mean_partial_kernel<float>, dim3(n_parts), dim3(256), 0, stream, static_cast<const float*>(A), nA, m, mean_parts);
+    else hipLaunchKernelGGL(mean_partial_kernel<double>, dim3(n_parts), dim3(256), 0, stream, static_cast<const double*>(A), nA, m, mean_parts);
+    p.mean_linv = mean_linv;
+  }
   bool rows_done = false;
   auto launch_chol = [&](auto zero, const void* src, int n, void* lt, void* li) {
     using T = decltype(zero);
@@ -675,10 +821,13 @@ static int pairwise_impl(const void* A, int nA, const void* B, int nB, int m, in
     T* ltp = static_cast<T*>(lt);
     T* lip = static_cast<T*>(li);
     int* rows = rows_done ? nullptr : p.row_start;  // the first prologue launch also writes the slab slot table
+    const bool with_mean = want_mean && src == A && !rows_done;   // the A-side launch carries the mean block
     rows_done = true;
-    if (m <= 16) hipLaunchKernelGGL((cholesky_kernel<T, 16>), dim3(n), dim3(256), 0, stream, sp, m, g.MR, ltp, lip, rows, p, g.TI);
-    else if (m <= 32) hipLaunchKernelGGL((cholesky_kernel<T, 32>), dim3(n), dim3(256), 0, stream, sp, m, g.MR, ltp, lip, rows, p, g.TI);
-    else hipLaunchKernelGGL((cholesky_kernel<T, 64>), dim3(n), dim3(256), 0, stream, sp, m, g.MR, ltp, lip, rows, p, g.TI);
+    const int blocks = n + (with_mean ? 1 : 0);
+    const double* mp = with_mean ? mean_parts : nullptr;
+    if (m <= 16) hipLaunchKernelGGL((cholesky_kernel<T, 16>), dim3(blocks), dim3(256), 0, stream, sp, m, g.MR, ltp, lip, rows, p, g.TI, n, mp, n_parts, mean_linv);
+    else if (m <= 32) hipLaunchKernelGGL((cholesky_kernel<T, 32>), dim3(blocks), dim3(256), 0, stream, sp, m, g.MR, ltp, lip, rows, p, g.TI, n, mp, n_parts, mean_linv);
+    else hipLaunchKernelGGL((cholesky_kernel<T, 64>), dim3(blocks), dim3(256), 0, stream, sp, m, g.MR, ltp, lip, rows, p, g.TI, n, mp, n_parts, mean_linv);
   };
   void* ws_lt = ws + w.off_lt;
   void* ws_li = ws + w.off_linv;
@@ -706,7 +855,7 @@ static int pairwise_impl(const void* A, int nA, const void* B, int nB, int m, in
 
   // K1: pair tiles
   EventPair ev{};
-  bool prof = g_profile;
+  bool prof = g_profile.load();
   if (prof) {  // event records do not belong in a captured graph: profile eager launches only
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) prof = false;
@@ -742,11 +891,11 @@ static int pairwise_impl(const void* A, int nA, const void* B, int nB, int m, in
   return SQFA_OK;
 }
 
-size_t sqfa_airm_workspace_bytes_sharded(int nA, int nB, int m, int dtype, int shard_count) {
+size_t sqfa_airm_workspace_bytes_sharded(int nA, int nB, int m, int dtype, int shard_count, int geometry_policy) {
   int ti, tj, nbi, nbj, mr;
   if (shard_count < 1 || sqfa_airm_tiling(nA, nB, m, dtype, &ti, &tj, &nbi, &nbj, &mr) != SQFA_OK) return 0;
   Geometry g;
-  find_geometry(m, dtype, pair_count(nA, nB, shard_count), &g);
+  find_geometry(m, dtype, pair_count(nA, nB, shard_count), &g, geometry_policy > 0 ? 1 : (geometry_policy < 0 ? -1 : 0));
   const int nBeff = nB == 0 ? nA : nB, self_mode = nB == 0 ? 1 : 0;
   return layout(nA, nBeff, g, dtype == SQFA_F32 ? 4 : 8, self_mode,
                 choose_tile_width(nA, nBeff, g, self_mode, shard_count), shard_count).total;
@@ -759,18 +908,94 @@ int sqfa_airm_pairwise(const void* A, int nA, const void* B, int nB, int m, int 
                        void* workspace, size_t workspace_bytes, void* stream_) {
   return pairwise_impl(A, nA, B, nB, m, dtype, scale, eps, sqrt_mode, pair_weights, uniform_weight, shard_index,
                        shard_count, loss_out, gradA_out, gradB_out, dist_out, eig_out, nonfinite_out, workspace,
-                       workspace_bytes, stream_, nullptr);
+                       workspace_bytes, stream_, nullptr, nullptr);
+}
+
+int sqfa_airm_pairwise_opt(const void* A, int nA, const void* B, int nB, int m, int dtype, double scale,
+                           double eps, int sqrt_mode, const void* pair_weights, double uniform_weight,
+                           int shard_index, int shard_count, void* loss_out, void* gradA_out,
+                           void* gradB_out, void* dist_out, void* eig_out, int* nonfinite_out,
+                           void* workspace, size_t workspace_bytes, void* stream_, const sqfa_airm_options* options) {
+  return pairwise_impl(A, nA, B, nB, m, dtype, scale, eps, sqrt_mode, pair_weights, uniform_weight, shard_index,
+                       shard_count, loss_out, gradA_out, gradB_out, dist_out, eig_out, nonfinite_out, workspace,
+                       workspace_bytes, stream_, nullptr, options);
 }
 
 int sqfa_airm_eigenvalues_backward(const void* A, int nA, const void* B, int nB, int m, int dtype,
                                    const void* eig_weights, void* gradA_out, void* gradB_out,
-                                   void* workspace, size_t workspace_bytes, void* stream_) {
+                                   void* workspace, size_t workspace_bytes, void* stream_,
+                                   const sqfa_airm_options* options) {
   if (eig_weights == nullptr || gradA_out == nullptr) {
     g_last_error[0] = 0;
     return fail(SQFA_ERR_BAD_ARGUMENT, "eig_weights / gradA_out", hipSuccess);
   }
   return pairwise_impl(A, nA, B, nB, m, dtype, 1.0, 0.0, 0, nullptr, 0.0, 0, 1, nullptr, gradA_out, gradB_out,
-                       nullptr, nullptr, nullptr, workspace, workspace_bytes, stream_, eig_weights);
+                       nullptr, nullptr, nullptr, workspace, workspace_bytes, stream_, eig_weights, options);
+}
+
+size_t sqfa_spd_function_workspace_bytes(int n, int m, int dtype) {
+  Geometry g;
+  if (n < 1 || m < 1 || (dtype != SQFA_F32 && dtype != SQFA_F64) || !find_geometry(m, dtype, -1, &g, -1)) return 0;
+  return align_up((size_t)n * g.MR * g.MR * (dtype == SQFA_F32 ? 4 : 8));
+}
+
+int sqfa_spd_function(const void* S, int n, int m, int dtype, int kind, void* F_out, double* U_out, double* lam_out,
+                      void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  g_last_error[0] = 0;
+  if (S == nullptr || n < 1 || m < 1 || U_out == nullptr || lam_out == nullptr || workspace == nullptr)
+    return fail(SQFA_ERR_BAD_ARGUMENT, "null/size argument", hipSuccess);
+  if (dtype != SQFA_F32 && dtype != SQFA_F64) return fail(SQFA_ERR_BAD_ARGUMENT, "dtype", hipSuccess);
+  if (kind != SQFA_SPD_LOG && kind != SQFA_SPD_SQRT && kind != SQFA_SPD_INV_SQRT) return fail(SQFA_ERR_BAD_ARGUMENT, "kind", hipSuccess);
+  Geometry g;
+  if (!find_geometry(m, dtype, -1, &g, -1) || g.eig == nullptr) return fail(SQFA_ERR_UNSUPPORTED_M, "matrix size not supported", hipSuccess);
+  if (workspace_bytes < sqfa_spd_function_workspace_bytes(n, m, dtype)) return fail(SQFA_ERR_WORKSPACE, "workspace too small", hipSuccess);
+  PairParams p;
+  memset(&p, 0, sizeof(p));
+  // Cholesky factor of every class, columns contiguous, identity padded to the size class (K0; double inside)
+  auto chol = [&](auto zero) {
+    using T = decltype(zero);
+    const T* sp = static_cast<const T*>(S);
+    T* ltp = static_cast<T*>(workspace);
+    if (m <= 16) hipLaunchKernelGGL((cholesky_kernel<T, 16>), dim3(n), dim3(256), 0, stream, sp, m, g.MR, ltp, (T*)nullptr, (int*)nullptr, p, g.TI);
+    else if (m <= 32) hipLaunchKernelGGL((cholesky_kernel<T, 32>), dim3(n), dim3(256), 0, stream, sp, m, g.MR, ltp, (T*)nullptr, (int*)nullptr, p, g.TI);
+    else hipLaunchKernelGGL((cholesky_kernel<T, 64>), dim3(n), dim3(256), 0, stream, sp, m, g.MR, ltp, (T*)nullptr, (int*)nullptr, p, g.TI);
+  };
+  if (dtype == SQFA_F32) chol(0.0f); else chol(0.0);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(SQFA_ERR_LAUNCH, "cholesky_kernel", e);
+  e = g.eig(workspace, n, m, U_out, lam_out, stream);
+  if (e != hipSuccess) return fail(SQFA_ERR_LAUNCH, "class_eig_kernel", e);
+  if (F_out != nullptr) {
+    const size_t lds = ((size_t)m * m + m) * sizeof(double);
+    if (dtype == SQFA_F32) hipLaunchKernelGGL(spd_function_kernel<float>, dim3(n), dim3(256), lds, stream, U_out, lam_out, m, kind, static_cast<float*>(F_out));
+    else hipLaunchKernelGGL(spd_function_kernel<double>, dim3(n), dim3(256), lds, stream, U_out, lam_out, m, kind, static_cast<double*>(F_out));
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(SQFA_ERR_LAUNCH, "spd_function_kernel", e);
+  }
+  return SQFA_OK;
+}
+
+int sqfa_spd_function_backward(const double* U, const double* lam, const void* G, int n, int m, int dtype, int kind,
+                               void* gradS_out, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  g_last_error[0] = 0;
+  if (U == nullptr || lam == nullptr || G == nullptr || gradS_out == nullptr || n < 1 || m < 1)
+    return fail(SQFA_ERR_BAD_ARGUMENT, "null/size argument", hipSuccess);
+  if (dtype != SQFA_F32 && dtype != SQFA_F64) return fail(SQFA_ERR_BAD_ARGUMENT, "dtype", hipSuccess);
+  if (kind != SQFA_SPD_LOG && kind != SQFA_SPD_SQRT && kind != SQFA_SPD_INV_SQRT) return fail(SQFA_ERR_BAD_ARGUMENT, "kind", hipSuccess);
+  if (m > max_dim()) return fail(SQFA_ERR_UNSUPPORTED_M, "matrix size not supported", hipSuccess);
+  const size_t lds = ((size_t)3 * m * m + m) * sizeof(double);   // 96.5 KB at m = 64
+  if (dtype == SQFA_F32) {
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spd_function_backward_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(spd_function_backward_kernel<float>, dim3(n), dim3(256), lds, stream, U, lam, static_cast<const float*>(G), m, kind, static_cast<float*>(gradS_out));
+  } else {
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spd_function_backward_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(spd_function_backward_kernel<double>, dim3(n), dim3(256), lds, stream, U, lam, static_cast<const double*>(G), m, kind, static_cast<double*>(gradS_out));
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(SQFA_ERR_LAUNCH, "spd_function_backward_kernel", e);
+  return SQFA_OK;
 }
 
 }  // extern "C"

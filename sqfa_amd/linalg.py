@@ -1,7 +1,9 @@
 """SPD matrix algebra with the reference's public names (src/sqfa/linalg.py).
 
-``generalized_eigenvalues`` runs on the HIP pair kernel; the remaining helpers are not on
-the hot path and are thin torch expressions that work on any device.
+``generalized_eigenvalues`` runs on the HIP pair kernel; ``spd_log`` / ``spd_sqrt`` of GPU tensors run on the native
+per-class eigen-decomposition (sqfa_spd_function: Cholesky + one-sided Jacobi, closed-form backward) -- the building
+block of ``log_euclidean``; CPU tensors, and the remaining helpers (not on the hot path, SURVEY.md
+section 2), are thin torch expressions.
 """
 import torch
 
@@ -61,12 +63,17 @@ def _sym_eig_fn(M, fn):
 
 
 def spd_sqrt(M):
-    """Symmetric square root (reference: src/sqfa/linalg.py:121-141)."""
+    """Symmetric square root (reference: src/sqfa/linalg.py:121-141).  GPU tensors: sqfa_spd_function (HIP)."""
+    if _native.spd_function_supported(M):
+        return _native.spd_function(M, _native.SPD_SQRT)
     return _sym_eig_fn(M, torch.sqrt)
 
 
 def spd_log(M):
-    """Matrix logarithm of SPD matrices (reference: src/sqfa/linalg.py:165-183)."""
+    """Matrix logarithm of SPD matrices (reference: src/sqfa/linalg.py:165-183).  GPU tensors: sqfa_spd_function (HIP),
+    differentiable in closed form (finite also for repeated eigenvalues, where eigh's autograd is not)."""
+    if _native.spd_function_supported(M):
+        return _native.spd_function(M, _native.SPD_LOG)
     return _sym_eig_fn(M, torch.log)
 
 

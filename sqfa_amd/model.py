@@ -46,13 +46,34 @@ def _check_statistics(data_statistics, needs_dict=False):
         )
 
 
+_scatter_cache = {}   # (id(cov), id(mu)) -> (weakref cov, weakref mu, versions, second moments); entries die with their inputs
+
+
 def _stats_to_scatter(statistics):
-    """Second-moment matrices from either input form (reference: model.py:24-53)."""
+    """Second-moment matrices from either input form (reference: model.py:24-53).  For a dict the (C,D,D) sum
+    cov + mu mu^T is formed ONCE per pair of input tensors (and versions) and the same tensor object is handed out
+    again: the reference recomputes it inside every call, and a fresh tensor per call would also make
+    every get_class_distances / transform_scatters call re-check the symmetry of (C,D,D) values."""
     if not isinstance(statistics, dict):
         return statistics
     _check_statistics(statistics)
-    mu = statistics["means"]
-    return statistics["covariances"] + mu[:, :, None] * mu[:, None, :]
+    mu, cov = statistics["means"], statistics["covariances"]
+    if not (torch.is_tensor(mu) and torch.is_tensor(cov)) or mu.requires_grad or cov.requires_grad:
+        return cov + mu[:, :, None] * mu[:, None, :]
+    import weakref
+    key = (id(cov), id(mu))
+    hit = _scatter_cache.get(key)
+    if hit is not None and hit[0]() is cov and hit[1]() is mu and hit[2] == (cov._version, mu._version):
+        return hit[3]
+    out = cov + mu[:, :, None] * mu[:, None, :]
+    drop = lambda _r, k=key: _scatter_cache.pop(k, None)
+    try:
+        _scatter_cache[key] = (weakref.ref(cov, drop), weakref.ref(mu, drop), (cov._version, mu._version), out)
+    except TypeError:
+        pass
+    while len(_scatter_cache) > 4:            # a handful of live statistics at most (each entry holds C*D*D values)
+        _scatter_cache.pop(next(iter(_scatter_cache)))
+    return out
 
 
 class SecondMomentsSQFA(nn.Module):

@@ -20,12 +20,21 @@ def replicas_agree(tensors, group=None):
     distributed).  This is the check that would notice if that ever stopped holding: an exact integer checksum
     of the bit patterns, compared with one MAX all-reduce of [h, -h] (= max and -min of the checksums)."""
     h = None
+    views = {1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.int64}
     for t in tensors:
-        bits = t.detach().contiguous().view(torch.int32 if t.element_size() == 4 else torch.int64)
+        view = views.get(t.element_size())
+        if view is None or t.is_complex():
+            import warnings
+            warnings.warn(f"sqfa_amd.replicas_agree: skipping a {t.dtype} tensor (no integer view of its bit pattern)")
+            continue
+        bits = t.detach().contiguous().view(view)
         # position-weighted so that permuted or compensating differences do not cancel
         w = torch.arange(1, bits.numel() + 1, dtype=torch.int64, device=bits.device)
         part = (bits.reshape(-1).to(torch.int64) * w).sum()
         h = part if h is None else h * 1000003 + part
+    if h is None:
+        return True
+    # (int64 wraps around on overflow, identically on every rank: the checksum stays an exact function of the bits)
     both = torch.stack([h, -h])
     dist.all_reduce(both, op=dist.ReduceOp.MAX, group=group)
     return bool((both[0] == -both[1]).item())

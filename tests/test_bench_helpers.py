@@ -33,8 +33,11 @@ def test_workload_generator_matches_explicit_projection():
 
 def test_cpu_baseline_leg_runs_the_oracle():
     S, scale = bench.make_feature_scatters(12, 30, 3, "smsqfa", torch.device("cpu"), torch.float32)
-    out = bench.cpu_baseline(S, scale, 12, seconds_budget=0.5)
+    out = bench.cpu_baseline(S, scale, 12)
     assert out["kind"] == "port" and out["unit"] == "evals/s" and out["value"] > 0 and out["cores"] >= 1
+    assert out["full_size"] is True and out["cores"] == bench._entitled_threads() and out["cpu_model"]
+    one = out["one_thread"]
+    assert one["cores"] == 1 and one["full_size"] is False and one["value"] > 0
     json.dumps(out)
 
 

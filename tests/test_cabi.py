@@ -88,8 +88,8 @@ def test_argument_validation_of_the_round2_entry_points():
     lib = _lib.load()
     z, fake = ctypes.c_void_p(0), ctypes.c_void_p(4096)
     # eigenvalue backward: needs weights and an output
-    assert lib.sqfa_airm_eigenvalues_backward(fake, 4, fake, 4, 4, 0, z, fake, fake, fake, 1 << 30, z) == -1
-    assert lib.sqfa_airm_eigenvalues_backward(fake, 4, fake, 4, 4, 0, fake, z, fake, fake, 1 << 30, z) == -1
+    assert lib.sqfa_airm_eigenvalues_backward(fake, 4, fake, 4, 4, 0, z, fake, fake, fake, 1 << 30, z, None) == -1
+    assert lib.sqfa_airm_eigenvalues_backward(fake, 4, fake, 4, 4, 0, fake, z, fake, fake, 1 << 30, z, None) == -1
     # Gaussian pair terms: null inputs, bad dtype, too large, gradient outputs without upstream gradients
     assert lib.sqfa_gauss_pair_terms(z, fake, 3, fake, fake, 3, 4, 0, z, z, fake, fake, z, z, z) == -1
     assert lib.sqfa_gauss_pair_terms(fake, fake, 3, fake, fake, 3, 4, 9, z, z, fake, fake, z, z, z) == -1
@@ -114,6 +114,20 @@ def test_argument_validation_of_the_round2_entry_points():
     assert lib.sqfa_lbfgs_direction(fake, fake, fake, 10, 10, slots, 2, fake, z, fake, fake, 0, z) == -1   # bad slot
     # per-shard workspace: never more than the any-shard bound, and decreasing with the shard's share
     any_shards = lib.sqfa_airm_workspace_bytes(1000, 0, 16, 0)
-    one, eight = lib.sqfa_airm_workspace_bytes_sharded(1000, 0, 16, 0, 1), lib.sqfa_airm_workspace_bytes_sharded(1000, 0, 16, 0, 8)
+    one, eight = lib.sqfa_airm_workspace_bytes_sharded(1000, 0, 16, 0, 1, 0), lib.sqfa_airm_workspace_bytes_sharded(1000, 0, 16, 0, 8, 0)
     assert 0 < eight < one <= any_shards and one < 60e6
-    assert lib.sqfa_airm_workspace_bytes_sharded(1000, 0, 16, 0, 0) == 0
+    assert lib.sqfa_airm_workspace_bytes_sharded(1000, 0, 16, 0, 0, 0) == 0
+    # the any-policy size covers either lane geometry of a small launch, whichever policy a call will carry
+    for m in (8, 12, 16, 17, 20, 32):
+        for dt in (0, 1):
+            anyp = lib.sqfa_airm_workspace_bytes(30, 0, m, dt)
+            assert anyp >= max(lib.sqfa_airm_workspace_bytes_sharded(30, 0, m, dt, 1, pol) for pol in (-1, 0, 1)) > 0
+    # per-class matrix functions (round 4)
+    assert lib.sqfa_spd_function_workspace_bytes(10, 16, 0) >= 10 * 16 * 16 * 4
+    assert lib.sqfa_spd_function_workspace_bytes(10, 65, 0) == 0 and lib.sqfa_spd_function_workspace_bytes(0, 4, 0) == 0
+    assert lib.sqfa_spd_function(z, 3, 4, 0, 0, fake, fake, fake, fake, 1 << 20, z) == -1            # null S
+    assert lib.sqfa_spd_function(fake, 3, 4, 0, 7, fake, fake, fake, fake, 1 << 20, z) == -1         # kind
+    assert lib.sqfa_spd_function(fake, 3, 65, 0, 0, fake, fake, fake, fake, 1 << 20, z) == -2        # m > 64
+    assert lib.sqfa_spd_function(fake, 3, 4, 0, 0, fake, fake, fake, fake, 8, z) == -3               # workspace
+    assert lib.sqfa_spd_function_backward(fake, fake, z, 3, 4, 0, 0, fake, z) == -1                  # null G
+    assert lib.sqfa_spd_function_backward(fake, fake, fake, 3, 65, 0, 0, fake, z) == -2

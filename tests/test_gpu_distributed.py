@@ -163,7 +163,17 @@ def _rccl_graph_worker(port, q):
                 packed, grad = closure.run()
                 outs.append(packed.detach().cpu().numpy().copy())
             eager, _ = closure.run(eager=True)
-            results[class_sharded] = (closure.state, [g is not None for g in closure.graphs or []], outs, eager.cpu().numpy())
+            # replay -> eager -> replay: after an eager pass the replays must still return the tensors the graphs
+            # write; with the filters changed in between, a stale eager tensor would show the OLD filters' gradient
+            raw = model.parametrizations.filters.original
+            with torch.no_grad():
+                raw.mul_(1.0 + 0.05 * torch.linspace(-1, 1, raw.numel(), dtype=raw.dtype, device=dev).view_as(raw))
+            after, after_grad = closure.run()
+            after = after.detach().cpu().numpy().copy()
+            after_grad = after_grad.detach().cpu().numpy().copy()
+            fresh, _ = ShardedClosure(model, prepared).run()      # an eager evaluation of a new object: the reference
+            results[class_sharded] = (closure.state, [g is not None for g in closure.graphs or []], outs, eager.cpu().numpy(),
+                                      after, after_grad, fresh.detach().cpu().numpy())
         q.put(results)
     finally:
         dist.destroy_process_group()
@@ -178,13 +188,17 @@ def test_graph_capture_with_live_rccl_communicator():
     results = q.get(timeout=500)
     p.join(timeout=60)
     assert p.exitcode == 0
-    for class_sharded, (state, graphs, outs, eager) in results.items():
+    for class_sharded, (state, graphs, outs, eager, after, after_grad, fresh) in results.items():
         assert state == "on", f"capture failed with a live RCCL communicator (class_sharded={class_sharded})"
         assert sum(graphs) == 4 and len(graphs) == 7           # four captured stages, three eager collectives
         for o in outs:
             assert np.array_equal(o, outs[0])                    # replays are bit-identical to the eager evaluations
         assert np.array_equal(eager, outs[0])
         assert np.isfinite(outs[0]).all() and outs[0][1] == 0 and outs[0][2] == 0
+        # replay after an eager pass, on changed filters: the graph's own tensors, not the eager pass's stale ones
+        assert not np.array_equal(after, outs[0])
+        assert np.array_equal(after, fresh)
+        assert np.array_equal(after_grad, fresh[3:].reshape(after_grad.shape))
 
 
 def _split_graph_worker(rank, world, port, q):

@@ -33,12 +33,10 @@ for m in (1, 2, 3, 4, 5, 7, 8, 9, 11, 12, 13, 16, 17, 18, 20, 23, 24, 25, 31, 32
 @pytest.fixture
 def class_factors_always():
     """Force the class factor pass (K0b) on: by default it only runs for launches with >= 1e4-1e5 pairs, far more than
-    these cases have (sqfa_airm_class_factor_policy, include/sqfa_hip.h)."""
-    from sqfa_amd import _lib
-    lib = _lib.load()
-    previous = lib.sqfa_airm_class_factor_policy(1)
-    yield
-    lib.sqfa_airm_class_factor_policy(previous)
+    these cases have (sqfa_airm_options::class_factor_policy, include/sqfa_hip.h: a per-call argument)."""
+    from sqfa_amd import _native
+    with _native.policies(class_factor=1):
+        yield
 
 
 @pytest.mark.parametrize("m,nA,nB,sqrt_mode,weighted,shards,f64", [c for c in CASES if c[0] >= 9])
@@ -51,12 +49,10 @@ def test_random_case_through_class_factor_pass(class_factors_always, m, nA, nB, 
 @pytest.fixture
 def regular_rows_only():
     """Keep small launches on the regular lane geometries: by default these cases (a few hundred pairs) run on the
-    small-launch rows of configs.hpp wherever one exists (sqfa_airm_geometry_policy, include/sqfa_hip.h)."""
-    from sqfa_amd import _lib
-    lib = _lib.load()
-    previous = lib.sqfa_airm_geometry_policy(-1)
-    yield
-    lib.sqfa_airm_geometry_policy(previous)
+    small-launch rows of configs.hpp wherever one exists (sqfa_airm_options::geometry_policy, include/sqfa_hip.h)."""
+    from sqfa_amd import _native
+    with _native.policies(geometry=-1):
+        yield
 
 
 @pytest.mark.parametrize("m,nA,nB,sqrt_mode,weighted,shards,f64", [c for c in CASES if (c[0] <= 20 or 25 <= c[0] <= 32) and not c[6]])
@@ -75,15 +71,12 @@ def test_small_launch_and_regular_rows_agree(m):
     C = 30
     A = torch.tensor(spd(rng, C, m), dtype=torch.float32, device=DEV)
     outs = {}
-    first = lib.sqfa_airm_geometry_policy(-1)
-    try:
-        for mode in (-1, 1):
-            assert lib.sqfa_airm_geometry_policy(mode) in (-1, 1)
-            assert lib.sqfa_airm_workspace_bytes(C, 0, m, 0) >= lib.sqfa_airm_workspace_bytes_sharded(C, 0, m, 0, 1) > 0
+    for mode in (-1, 1):
+        # the any-policy size covers the size of either row, whichever is asked for first
+        assert lib.sqfa_airm_workspace_bytes(C, 0, m, 0) >= lib.sqfa_airm_workspace_bytes_sharded(C, 0, m, 0, 1, mode) > 0
+        with _native.policies(geometry=mode):
             outs[mode] = _native.hip_pair_backend(A, None, scale=1.0, eps=1e-6, sqrt_mode=True, weights=None, uniform_weight=1.0,
                                                   shard=(0, 1), want_loss=True, want_grad=True, want_dist=True, want_eig=True)
-    finally:
-        lib.sqfa_airm_geometry_policy(first)
     reg, small = outs[-1], outs[1]
     assert small["nonfinite"].tolist() == [0, 0]
     assert abs(small["loss"].item() - reg["loss"].item()) <= 2e-6 * abs(reg["loss"].item())
@@ -215,14 +208,10 @@ def test_class_factor_pass_on_and_off_agree(m, f64):
     dtype = torch.float64 if f64 else torch.float32
     A = torch.tensor(spd(rng, C, m), dtype=dtype, device=DEV)
     outs = {}
-    first = lib.sqfa_airm_class_factor_policy(-1)
-    try:
-        for mode in (-1, 1):
-            assert lib.sqfa_airm_class_factor_policy(mode) in (-1, 1)
+    for mode in (-1, 1):
+        with _native.policies(class_factor=mode):
             outs[mode] = _native.hip_pair_backend(A, None, scale=1.0, eps=1e-6, sqrt_mode=True, weights=None, uniform_weight=1.0,
                                                   shard=(0, 1), want_loss=True, want_grad=True, want_dist=True, want_eig=False)
-    finally:
-        lib.sqfa_airm_class_factor_policy(first)
     off, on = outs[-1], outs[1]
     assert on["nonfinite"].tolist() == [0, 0]
     ltol, gtol = (1e-12, 1e-10) if f64 else (1e-6, 2e-5)

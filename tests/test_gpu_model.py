@@ -286,6 +286,16 @@ def test_c5_config_full_fit_prefix_matches_reference_f64():
     print("   per-epoch |loss - reference|:", np.abs(loss[:len(ref)] - ref[:len(loss)]).round(8))
     assert np.isfinite(loss).all()
     assert np.abs(loss[:6] - ref[:6]).max() < 1e-6
+    # hard sanity bound on the END of the run: a fit that diverged after the sixth epoch must not pass on finite
+    # losses alone.  The reference's own end points on record -- unperturbed (G7), its Cholesky route (G7b), two 1e-14
+    # perturbed starts (G7c), 1e-12 / 1e-10 / 1e-8 perturbed starts (G7d) -- span final losses -5.954 ... -1.808 and
+    # 12 ... 15 epochs; the GPU run must end inside that span (1e-3 margin, epochs +-2), at a loss below its start.
+    G7B, G7C, G7D = (load_golden(n) for n in ("g7b_fit_c5_wellposed.npz", "g7c_fit_c5_ensemble.npz", "g7d_fit_c5_ensemble2.npz"))
+    finals = np.concatenate([[ref[-1], G7B["sqfa_cholroute_loss"][-1]], G7C["sqfa_final_loss"], G7D["sqfa_final_loss"]])
+    epochs = np.concatenate([[len(ref), len(G7B["sqfa_cholroute_loss"])], G7C["sqfa_epochs"], G7D["sqfa_epochs"]])
+    assert finals.min() - 1e-3 <= loss[-1] <= finals.max() + 1e-3, (loss[-1], finals)
+    assert epochs.min() - 2 <= len(loss) <= epochs.max() + 2, (len(loss), epochs)
+    assert loss[-1] < loss[0]
 
 
 @pytest.mark.xfail(strict=False, reason="ensemble membership of a chaotic end point: the reference itself leaves its own "

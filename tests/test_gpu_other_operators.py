@@ -2,9 +2,9 @@
 gradients computed by the reference (golden G5b, tests/golden/make_golden.py:g5b):
 bhattacharyya / mahalanobis[_sq] / hellinger / fisher_rao_same_cov through the native Gaussian pair
 kernel (sqfa_gauss_pair_terms), log_euclidean[_sq] through per-class logarithms + exact pairwise
-distances.  Tolerances: float64 1e-9 (values) / 1e-8 (gradients); float32: max(3e-5, 5 x the
+distances.  Tolerances: float64 1e-9 (values) / 1e-8 (gradients); float32: max(1e-5, 5 x the
 reference's own float32-vs-float64 deviation on that case, golden G5b's f32 keys) -- the same rule as the
-affine-invariant family (tests/test_gpu_parity.py:_tols)."""
+affine-invariant family (tests/test_gpu_parity.py:_tols; 1e-5 is north_star's bound, 3e-5 until round 4)."""
 import numpy as np
 import pytest
 import torch
@@ -18,7 +18,7 @@ CASES = [tuple(int(v) for v in c) for c in G5B["cases"]]
 GAUSS_OPS = ("bhattacharyya", "mahalanobis_sq", "mahalanobis", "hellinger", "fisher_rao_same_cov")
 
 
-def _tol(key, name, what, dtype, floor64, floor32=3e-5):
+def _tol(key, name, what, dtype, floor64, floor32=1e-5):
     if dtype == torch.float64:
         return floor64
     dev = rel_err(G5B[f"{key}_{name}{what}_f32"], G5B[f"{key}_{name}{what}_f64"])
@@ -69,8 +69,11 @@ def test_gaussian_pair_operators_vs_reference(nA, nB, K, name, dtype):
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("name", ["log_euclidean_sq", "log_euclidean"])
 @pytest.mark.parametrize("nA,nB,K", CASES)
-def test_log_euclidean_vs_reference(nA, nB, K, name, dtype):
+def test_log_euclidean_vs_reference(nA, nB, K, name, dtype, monkeypatch):
+    """Values AND gradients of the reference (golden G5b) through the native per-class eigensolver (sqfa_spd_function /
+    sqfa_spd_function_backward): torch.linalg.eigh (rocSOLVER) must not be reached on the GPU path."""
     from sqfa_amd import distances
+    monkeypatch.setattr(torch.linalg, "eigh", lambda *a, **k: (_ for _ in ()).throw(AssertionError("library eigh on the GPU path")))
     key = f"A{nA}_B{nB}_K{K}"
     a, b = _inputs(key, nB, dtype)
     D = getattr(distances, name)(a["covariances"], b["covariances"])
@@ -81,7 +84,7 @@ def test_log_euclidean_vs_reference(nA, nB, K, name, dtype):
     wrt = [("gcovA", a["covariances"])] + ([("gcovB", b["covariances"])] if nB else [])
     grads = torch.autograd.grad((W.reshape(D.shape) * D).sum(), [t for _, t in wrt])
     for (gname, _), g in zip(wrt, grads):
-        assert rel_err(g.cpu(), G5B[f"{key}_{name}_{gname}_f64"]) <= _tol(key, name, f"_{gname}", dtype, 1e-7, 1e-3)
+        assert rel_err(g.cpu(), G5B[f"{key}_{name}_{gname}_f64"]) <= _tol(key, name, f"_{gname}", dtype, 1e-8, 1e-5)
 
 
 def test_gaussian_operators_large_batch_properties():

@@ -3,8 +3,9 @@ from the reference and against the CPU oracles.  Run with ``-m gpu`` on an MI355
 
 Tolerances (relative Frobenius unless noted):
   float64: loss 1e-11, distances 1e-10, gradients 1e-8  (one-sided Jacobi vs LAPACK)
-  float32: loss 1e-5 (BASELINE.json north_star), distances 2e-5 abs, gradients: max(3e-5, 5x the
-           reference's own float32-vs-float64 deviation on the same input) -- SURVEY.md 8c.
+  float32: loss 1e-5 (BASELINE.json north_star), distances 2e-5 abs, gradients: max(1e-5, 5x the
+           reference's own float32-vs-float64 deviation on the same input) -- SURVEY.md 8c; 1e-5 is north_star's bound
+           (the floor was 3e-5 until round 4; observed 2e-7 ... 7e-7).
 """
 import numpy as np
 import pytest
@@ -42,7 +43,7 @@ def _tols(dtype, key=None, gkey="grad"):
     ref_dev = 0.0
     if key is not None:
         ref_dev = rel_err(G1[f"{key}_{gkey}_f32"], G1[f"{key}_{gkey}_f64"])
-    return dict(loss=1e-5, dist=2e-5, grad=max(3e-5, 5 * ref_dev))
+    return dict(loss=1e-5, dist=2e-5, grad=max(1e-5, 5 * ref_dev))
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
@@ -104,7 +105,7 @@ def test_cross_batches_vs_golden(nA, nB, m, dtype):
         gA, gB = torch.autograd.grad(loss, (A, B))
         dev_ref = max(rel_err(G1X[f"{key}_gA_{name}_f32"], G1X[f"{key}_gA_{name}_f64"]),
                       rel_err(G1X[f"{key}_gB_{name}_f32"], G1X[f"{key}_gB_{name}_f64"]))
-        gtol = 1e-8 if f64 else max(3e-5, 5 * dev_ref)
+        gtol = 1e-8 if f64 else max(1e-5, 5 * dev_ref)
         assert rel_err(gA.cpu(), G1X[f"{key}_gA_{name}_f64"]) <= gtol
         assert rel_err(gB.cpu(), G1X[f"{key}_gB_{name}_f64"]) <= gtol
 
@@ -125,7 +126,7 @@ def test_generalized_eigenvalues_gradient_vs_golden(nA, nB, m, dtype):
     gA, gB = torch.autograd.grad((Wl * lam).sum(), (A, B))
     dev_ref = max(rel_err(G1X[f"{key}_gA_lam_f32"], G1X[f"{key}_gA_lam_f64"]),
                   rel_err(G1X[f"{key}_gB_lam_f32"], G1X[f"{key}_gB_lam_f64"]))
-    gtol = 1e-8 if f64 else max(3e-5, 5 * dev_ref)
+    gtol = 1e-8 if f64 else max(1e-5, 5 * dev_ref)
     assert rel_err(gA.cpu(), G1X[f"{key}_gA_lam_f64"]) <= gtol
     assert rel_err(gB.cpu(), G1X[f"{key}_gB_lam_f64"]) <= gtol
 
@@ -181,7 +182,7 @@ def test_fisher_rao_vs_golden(C, K, dtype):
         sfx = "" if tag == "fr" else "_sq"
         dev_ref = max(rel_err(G2[f"{key}_gmu{sfx}_f32"], G2[f"{key}_gmu{sfx}_f64"]),
                       rel_err(G2[f"{key}_gcov{sfx}_f32"], G2[f"{key}_gcov{sfx}_f64"]))
-        gtol = 1e-8 if f64 else max(3e-5, 5 * dev_ref)
+        gtol = 1e-8 if f64 else max(1e-5, 5 * dev_ref)
         assert rel_err(gmu.cpu(), G2[f"{key}_gmu{sfx}_f64"]) <= gtol
         assert rel_err(gcov.cpu(), G2[f"{key}_gcov{sfx}_f64"]) <= gtol
 
@@ -272,14 +273,16 @@ def test_medium_sizes_vs_closed_form_oracle(C, m, dtype):
     assert flags.tolist() == [0, 0]
     f64 = dtype == torch.float64
     assert abs(loss.item() - loss_ref) <= (1e-11 if f64 else 1e-5) * abs(loss_ref)
-    assert rel_err(grad.cpu(), grad_ref) <= (1e-8 if f64 else 5e-5)
+    assert rel_err(grad.cpu(), grad_ref) <= (1e-8 if f64 else 1e-5)
 
 
 @pytest.mark.parametrize("C,m", [(1000, 16), (1000, 17), (1000, 32), (1000, 33)])
-def test_full_size_properties(C, m):
+def test_full_size_properties(C, m, record_property):
     """BASELINE configs c3 / c3-SQFA / c4 / c4-SQFA sizes (C=1000, m=16, 17, 32, 33):
-    size-independent properties instead of an oracle run: congruence invariance
-    d(G S G^T) = d(S), inversion invariance, gradient sums, float32 against float64."""
+    size-independent properties instead of a full oracle run -- congruence invariance
+    d(G S G^T) = d(S), inversion invariance, gradient sums, float32 against float64 -- AND a sampled comparison with the
+    oracle at the BASELINE size itself: 300 random pairs' distances and the complete gradient rows of three classes
+    (each the sum over its 999 pairs) against oracle/closed_form.py, float64 and float32."""
     torch.manual_seed(0)
     X = torch.randn(C, 4 * m, m, dtype=torch.float64)
     S = (X.transpose(1, 2) @ X / (4 * m) + 0.05 * torch.eye(m, dtype=torch.float64)).to(DEV)
@@ -295,7 +298,33 @@ def test_full_size_properties(C, m):
     # float32 run agrees with the float64 run
     l32, g32, _ = _fused(S.float())
     assert abs(l32.item() - l0.item()) < 1e-5 * abs(l0.item())
-    assert rel_err(g32.cpu(), g0.cpu()) < 5e-5
+    e32 = rel_err(g32.cpu(), g0.cpu())
+    record_property("grad_f32_vs_f64", e32)
+    assert e32 < 1e-5
+    # sampled oracle comparison at full size
+    from sqfa_amd import _native
+    rng = np.random.default_rng(1000 * m)
+    Snp = S.cpu().numpy()
+    pi = rng.integers(0, C, size=300)
+    pj = (pi + rng.integers(1, C, size=300)) % C                      # j != i
+    d_ref = np.array([closed_form.pairwise(Snp[[i]], Snp[[j]])[0][0, 0] for i, j in zip(pi, pj)])
+    rows = sorted({0, C - 1, int(rng.integers(1, C - 1))})            # first, last (ragged tile edges) and a random class
+    P = C * (C - 1) // 2
+    W = np.full((len(rows), C), -1.0 / P)
+    _, g_rows, _ = closed_form.pairwise(Snp[rows], Snp, W)             # class i against all j (the self pair contributes 0)
+    for dtype, dtol, gtol in ((torch.float64, 1e-10, 1e-8), (torch.float32, 1e-5, 1e-5)):
+        Sd = S.to(dtype)
+        out = _native.hip_pair_backend(Sd, None, scale=1.0, eps=1e-6, sqrt_mode=True, weights=None, uniform_weight=-1.0 / P,
+                                       shard=(0, 1), want_loss=True, want_grad=True, want_dist=True, want_eig=False)
+        assert out["nonfinite"].tolist() == [0, 0]
+        d = out["dist"][torch.as_tensor(pi, device=DEV), torch.as_tensor(pj, device=DEV)].cpu().numpy()
+        e_d = np.abs(d - d_ref).max() / np.abs(d_ref).max()
+        e_g = max(rel_err(out["gradA"][r].cpu(), g_rows[k]) for k, r in enumerate(rows))
+        tag = "f64" if dtype == torch.float64 else "f32"
+        record_property(f"sampled_dist_err_{tag}", float(e_d))
+        record_property(f"sampled_grad_rows_err_{tag}", float(e_g))
+        print(f"C={C} m={m} {tag}: 300 sampled distances {e_d:.2e} (bound {dtol:g}), gradient rows {rows} {e_g:.2e} (bound {gtol:g})")
+        assert e_d <= dtol and e_g <= gtol, (tag, e_d, e_g)
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])

@@ -326,3 +326,79 @@ def test_other_operators_values_and_gradients_cpu_branch():
 
 def test_class_statistics_vs_reference_ragged_1000_classes():
     mc.check_class_statistics_vs_reference("cpu")
+
+
+def test_dict_statistics_second_moments_are_formed_once():
+    """_stats_to_scatter hands out the SAME tensor for the same (covariances, means) tensors and versions (the reference
+    rebuilds cov + mu mu^T inside every call; a fresh tensor per call also re-ran the symmetry check of the
+    native projection on every get_class_distances / transform_scatters call), and notices in-place edits."""
+    from sqfa_amd import model as M
+    g = torch.Generator().manual_seed(0)
+    A = torch.randn(4, 6, 9, generator=g)
+    stats = {"means": torch.randn(4, 6, generator=g), "covariances": A @ A.transpose(1, 2)}
+    a = M._stats_to_scatter(stats)
+    b = M._stats_to_scatter(dict(stats))              # another dict, the same tensors
+    assert a is b
+    assert torch.equal(a, stats["covariances"] + stats["means"][:, :, None] * stats["means"][:, None, :])
+    stats["means"].mul_(2.0)                          # in-place edit: version changes, the sum is rebuilt
+    c = M._stats_to_scatter(stats)
+    assert c is not a and torch.equal(c, stats["covariances"] + stats["means"][:, :, None] * stats["means"][:, None, :])
+    raw = torch.eye(3).repeat(2, 1, 1)
+    assert M._stats_to_scatter(raw) is raw            # tensors pass through
+    tracked = {"means": stats["means"].clone().requires_grad_(), "covariances": stats["covariances"]}
+    assert M._stats_to_scatter(tracked).requires_grad  # autograd-tracked inputs are never cached
+
+
+def test_sharded_closure_eager_pass_does_not_disturb_the_captured_graphs():
+    """ShardedClosure.run(eager=True) after the capture (bench.py's profiling pass) must leave the box bound to the tensors
+    the captured graphs write (it returned and all-reduced the stale eager tensors afterwards).  The stage /
+    graph mechanics with stand-ins for the HIP graphs: a 'graph' re-runs its stage's arithmetic INTO the tensors that were
+    bound when it was captured, exactly what a replay does."""
+    from sqfa_amd._optim import ShardedClosure
+    sc = ShardedClosure.__new__(ShardedClosure)
+    x = torch.zeros(3)
+    box = {}
+
+    def compute():                 # like stage_backward: binds a fresh tensor
+        box["grad"] = x * 2.0
+
+    def collective():              # like reduce_grad: reads the box at call time
+        box["grad"] += 1.0
+
+    def pack():
+        box["packed"] = box["grad"] + 0.0
+
+    class FakeGraph:
+        """Captured at construction: reads the tensors bound THEN (`reads`), writes into the tensors it produced THEN."""
+
+        def __init__(self, fn, reads, writes):
+            self.reads = {n: box[n] for n in reads}
+            fn()
+            self.bound = {n: box[n] for n in writes}
+            self.fn = fn
+
+        def replay(self):            # like a HIP graph: fixed addresses in, fixed addresses out, the box is not touched
+            saved = dict(box)
+            box.update(self.reads)
+            self.fn()
+            for n, t in self.bound.items():
+                t.copy_(box[n])
+            box.clear()
+            box.update(saved)
+
+    sc.stages, sc.box, sc.calls = [compute, collective, pack], box, 99
+    x.fill_(1.0)
+    graphs = [FakeGraph(compute, [], ["grad"]), None]
+    collective()
+    graphs.append(FakeGraph(pack, ["grad"], ["packed"]))
+    sc.graphs, sc.state = graphs, "on"
+    packed, grad = sc.run()
+    assert packed.tolist() == [3.0] * 3
+    x.fill_(5.0)
+    e_packed, e_grad = sc.run(eager=True)
+    assert e_packed.tolist() == [11.0] * 3
+    assert box["grad"] is graphs[0].bound["grad"] and box["packed"] is graphs[2].bound["packed"]   # the capture-time tensors again
+    x.fill_(7.0)
+    packed, grad = sc.run()
+    assert packed.tolist() == [15.0] * 3 and grad.tolist() == [15.0] * 3
+    assert packed is graphs[2].bound["packed"]

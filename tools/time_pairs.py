@@ -20,13 +20,13 @@ def run(C, K, sqfa, dtype, reps=5):
     P = C * (C - 1) // 2
     cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
     lib = _lib.load()
-    lib.sqfa_airm_set_sweep_counter(cnt.data_ptr())
+    _native.POLICY["sweep_counter"] = cnt
     f = lambda: _native.hip_pair_backend(S, None, scale=0.5 if sqfa else 1.0, eps=1e-6, sqrt_mode=True, weights=None,
                                          uniform_weight=-1.0 / P, shard=(0, 1), want_loss=True, want_grad=True,
                                          want_dist=False, want_eig=False)
     out = f(); torch.cuda.synchronize()
     c = cnt.tolist()
-    lib.sqfa_airm_set_sweep_counter(None)
+    _native.POLICY["sweep_counter"] = None
     ts = []
     for _ in range(reps):
         torch.cuda.synchronize(); t0 = time.perf_counter(); out = f(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)

@@ -19,8 +19,8 @@ for m in (12, 16, 17, 24, 32, 33):
     cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
     f = lambda: _native.hip_pair_backend(S, None, scale=1.0, eps=1e-6, sqrt_mode=True, weights=None, uniform_weight=-1.0 / P,
                                          shard=(0, 1), want_loss=True, want_grad=True, want_dist=False, want_eig=False)
-    lib.sqfa_airm_set_sweep_counter(cnt.data_ptr()); out = f(); torch.cuda.synchronize(); c = cnt.tolist()
-    lib.sqfa_airm_set_sweep_counter(None)
+    with _native.policies(sweep_counter=cnt):
+        out = f(); torch.cuda.synchronize(); c = cnt.tolist()
     ts = []
     for _ in range(5):
         torch.cuda.synchronize(); t0 = time.perf_counter(); out = f(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
