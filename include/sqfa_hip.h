@@ -78,9 +78,11 @@ size_t sqfa_airm_workspace_bytes_sharded(int nA, int nB, int m, int dtype, int s
  *                        to rounding either way; every shard of a job must pass the same value.
  *   sweep_counter        NULL, or a device buffer of two uint64 {sum of Jacobi sweeps, number of wave rounds} the tile
  *                        kernel adds to atomically (introspection for benchmarks)
- *   mean_metric_policy   when the factor pass runs, sizes up to 33 orthogonalise the factor columns in the metric of the MEAN
- *                        class (class_factor_mean_kernel: fewer sweeps for classes that share a dominant covariance):
- *                        0 = yes (default), -1 = plain inner product (A/B timing, tests) */
+ *   mean_metric_policy   1 = when the factor pass runs, sizes m <= 17 and m = 25..32 orthogonalise the factor columns in the
+ *                        metric of the MEAN class (class_factor_mean_kernel) instead of the plain inner product: 0.2-0.8
+ *                        fewer sweeps (-8 % at m = 16 / 17) for classes that share a dominant covariance, as real class
+ *                        statistics do; +1-3 % on classes scattered around a multiple of I (BASELINE's synthetic
+ *                        generator), hence opt-in.  0 (default) / -1 = off.  Every shard of a job passes the same value. */
 typedef struct sqfa_airm_options {
   int geometry_policy;
   int class_factor_policy;
@@ -170,6 +172,24 @@ int sqfa_airm_eigenvalues_backward(const void *A, int nA, const void *B, int nB,
  */
 int sqfa_project_scatters(const void *F, int K, int D, const void *Psi, int C, int dtype, void *T_out,
                           void *stream);
+
+/*
+ * The same product from BLOCK-TRIANGULAR PACKED statistics: symmetric Psi_c stored once (per fit) as its lower block
+ * triangle -- row blocks of 16 rows, each holding the 16 x 64 tiles of the column stripes up to and including its 64-wide
+ * diagonal block, contiguous -- so that every closure streams 51-54 % of the bytes of the full tensor (D = 784: 54.1 %,
+ * 2048: 51.6 %, 3072: 51.0 %) and the statistics need half the memory.  Both halves of the symmetric product come from
+ * the same tile (project_packed_kernel.hip); results agree with sqfa_project_scatters to rounding (other summation order).
+ *   sqfa_packed_scatter_elems(D)    elements per class of the packed form (0: D not supported)
+ *   sqfa_pack_scatters              Psi (C,D,D) -> packed_out (C, sqfa_packed_scatter_elems(D)); reads the LOWER triangle
+ *                                   and the diagonal blocks of Psi
+ *   sqfa_project_scatters_packed    T_out (C,D,K) = Psi_c F^T from the packed form
+ * float32, D % 16 == 0, 16 <= D <= 4096, K <= 64 (SQFA_ERR_UNSUPPORTED_M otherwise: keep the full tensor and
+ * sqfa_project_scatters).  One workgroup per class: meant for C >= a few hundred classes.
+ */
+size_t sqfa_packed_scatter_elems(int D);
+int sqfa_pack_scatters(const void *Psi, int C, int D, int dtype, void *packed_out, void *stream);
+int sqfa_project_scatters_packed(const void *F, int K, int D, const void *packed, int C, int dtype, void *T_out,
+                                 void *stream);
 
 /*
  * The two small products around it, each reading T (C,D,K) once:

@@ -63,6 +63,16 @@ PROTOTYPES = {
         [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
          ctypes.c_void_p, ctypes.c_void_p],
     ),
+    "sqfa_packed_scatter_elems": (ctypes.c_size_t, [ctypes.c_int]),
+    "sqfa_pack_scatters": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p],
+    ),
+    "sqfa_project_scatters_packed": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+         ctypes.c_void_p, ctypes.c_void_p],
+    ),
     "sqfa_feature_scatters": (
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,

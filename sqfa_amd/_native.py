@@ -36,7 +36,8 @@ def max_dim():
 #   geometry      0 small-launch lane geometries by pair count (default), 1 wherever one exists, -1 never
 #   class_factor  0 class factor pass K0b by pair count (default), 1 always, -1 never
 #   sweep_counter None, or an int64 CUDA tensor of two elements {sum of Jacobi sweeps, wave rounds} the kernel adds to
-#   mean_metric   0 the factor pass works in the metric of the mean class where it can (default), -1 plain inner product
+#   mean_metric   1 the factor pass works in the metric of the mean class where it can (opt-in: pays for classes that share a
+#                 dominant covariance, loses 1-3 % on BASELINE's synthetic generator); 0 (default) plain inner product
 POLICY = {"geometry": 0, "class_factor": 0, "sweep_counter": None, "mean_metric": 0}
 
 
@@ -451,6 +452,81 @@ def native_projection_supported(scatters, filters):
     )
 
 
+# ---- block-triangular packed statistics (sqfa_pack_scatters / sqfa_project_scatters_packed) ------------------------------
+# The symmetric (C,D,D) statistics are packed ONCE per prepared tensor (model._prepare_statistics) into their lower block
+# triangle; every closure then streams 51-54 % of the bytes.  The packed copy lives beside the caller's tensor (which the
+# caller owns and may free: statistics.pack_scatters hands the packed form out for that case).
+# Measured (tools/time_projection_packed.py, profiles/r4_projection_packed.txt; full tensor -> packed): c3 (C=1000, D=784, K=16)
+# 0.449 -> 0.353 ms, K=8 0.437 -> 0.327, D=1024 0.626 -> 0.551, D=2048 / K=16 2.71 -> 2.29, D=3072 / K=16 (C=500) 2.97 -> 2.51;
+# K=32 (c4) 3.02 -> 4.41 ms (two filter blocks: twice the exact-f32 MFMA work per byte, MFMA-bound) and C=100 (c5: one workgroup
+# per class leaves 60 % of the CUs idle) 0.59 -> 1.22 ms keep the full-tensor kernel.
+PACKED_PROJECTION = True
+PACKED_MIN_CLASSES = 256      # one workgroup per class: fewer classes than CUs leave the chip idle (c5: C=100 keeps the full kernel)
+PACKED_MAX_FILTERS = 16       # one 16-filter block: beyond it the packed kernel is MFMA-bound and loses to the full-tensor stream
+_packed_cache = {}            # id(scatters) -> (weakref, _version, packed tensor)
+
+
+def packed_supported(scatters):
+    return (PACKED_PROJECTION and scatters.is_cuda and scatters.dtype == torch.float32 and scatters.dim() == 3
+            and scatters.shape[-1] == scatters.shape[-2] and scatters.shape[-1] % 16 == 0 and 64 <= scatters.shape[-1] <= 4096
+            and scatters.shape[0] >= PACKED_MIN_CLASSES and scatters.is_contiguous() and scatters.data_ptr() % 16 == 0
+            and not scatters.requires_grad)
+
+
+def pack_scatters(scatters):
+    """(C,D,D) symmetric float32 scatters -> (C, packed_elems) block-triangular packed form (sqfa_pack_scatters)."""
+    lib = _lib.load()
+    C, D = scatters.shape[0], scatters.shape[-1]
+    n = lib.sqfa_packed_scatter_elems(D)
+    if n == 0:
+        raise ValueError(f"n_dim = {D} has no packed form (needs D % 16 == 0)")
+    with torch.cuda.device(scatters.device):
+        out = torch.empty((C, n), dtype=scatters.dtype, device=scatters.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(scatters.device).cuda_stream)
+        _lib.check(lib.sqfa_pack_scatters(_ptr(scatters), C, D, _dtype_code(scatters), _ptr(out), stream), "sqfa_pack_scatters")
+    return out
+
+
+def prepare_packed(scatters, n_filters):
+    """Pack `scatters` once (outside any graph capture) if the packed projection applies to it and to this filter count;
+    later projections of the same tensor object / version find the packed copy through packed_for."""
+    import weakref
+    if (not torch.is_tensor(scatters) or n_filters > PACKED_MAX_FILTERS or not packed_supported(scatters)
+            or torch.cuda.is_current_stream_capturing()):
+        return None
+    hit = packed_for(scatters)
+    if hit is not None:
+        return hit
+    if not _is_symmetric_batch(scatters):
+        return None
+    packed = pack_scatters(scatters)
+    key = id(scatters)
+    try:
+        ref = weakref.ref(scatters, lambda _r, k=key: _packed_cache.pop(k, None))
+    except TypeError:
+        return None
+    _packed_cache[key] = (ref, scatters._version, packed)
+    return packed
+
+
+def packed_for(scatters, n_filters=1):
+    hit = _packed_cache.get(id(scatters))
+    if (hit is not None and hit[0]() is scatters and hit[1] == scatters._version and PACKED_PROJECTION
+            and n_filters <= PACKED_MAX_FILTERS):
+        return hit[2]
+    return None
+
+
+def _launch_projection(lib, F, Psi, T, K, D, C, code, stream):
+    """T = Psi F^T: from the packed copy when one was prepared for this tensor, else from the full tensor."""
+    packed = packed_for(Psi, K)
+    if packed is not None:
+        _lib.check(lib.sqfa_project_scatters_packed(_ptr(F), K, D, _ptr(packed), C, code, _ptr(T), stream),
+                   "sqfa_project_scatters_packed")
+    else:
+        _lib.check(lib.sqfa_project_scatters(_ptr(F), K, D, _ptr(Psi), C, code, _ptr(T), stream), "sqfa_project_scatters")
+
+
 def backward_groups(C, D, cap=64):
     """Class groups of sqfa_feature_scatters_backward: the kernel wants ~3000 waves in flight (one per 16-column
     block and group; it is latency-bound), while the (groups, K, D) partial sums are re-read by the reduction that
@@ -494,8 +570,7 @@ class ProjectScatters(torch.autograd.Function):
             T = torch.empty((C, D, K), dtype=Psi.dtype, device=Psi.device)
             S = torch.empty((C, K, K), dtype=Psi.dtype, device=Psi.device)
             stream = ctypes.c_void_p(torch.cuda.current_stream(Psi.device).cuda_stream)
-            _lib.check(lib.sqfa_project_scatters(_ptr(F), K, D, _ptr(Psi), C, code, _ptr(T), stream),
-                       "sqfa_project_scatters")
+            _launch_projection(lib, F, scatters if scatters.is_contiguous() else Psi, T, K, D, C, code, stream)
             if C >= ProjectScatters.NATIVE_PRODUCTS_MIN_CLASSES:
                 _lib.check(lib.sqfa_feature_scatters(_ptr(F), K, D, _ptr(T), C, code, _ptr(S), stream),
                            "sqfa_feature_scatters")
@@ -569,7 +644,7 @@ def closure_stage_project(raw, scatters, means, noise, sphere, out_S=None):
         else:
             F, norms = X, None
         T = torch.empty((C, D, K), dtype=dt, device=dev)
-        _lib.check(lib.sqfa_project_scatters(_ptr(F), K, D, _ptr(Psi), C, code, _ptr(T), stream), "sqfa_project_scatters")
+        _launch_projection(lib, F, scatters, T, K, D, C, code, stream)   # keyed on the caller's tensor object (packed copy)
         msize = K + 1 if means is not None else K
         m = torch.matmul(means.detach(), F.t()).contiguous() if means is not None else None   # (C,K) projected means
         S = out_S if out_S is not None else torch.empty((C, msize, msize), dtype=dt, device=dev)

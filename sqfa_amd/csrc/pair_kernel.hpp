@@ -837,7 +837,8 @@ struct PairCfg {
 #ifndef SQFA_FACTOR_MEAN
 #define SQFA_FACTOR_MEAN 1
 #endif
-  static constexpr bool MEAN_METRIC = SQFA_FACTOR_MEAN && DENSE_FACTOR && MR_ <= 33;
+  // (m = 20 / 24 / 33: two stacked double slots per lane spill -- the pass took 0.3-0.5 ms there; not offered)
+  static constexpr bool MEAN_METRIC = SQFA_FACTOR_MEAN && DENSE_FACTOR && (MR_ <= 17 || MR_ == 32);
   // The pass is a handful of lone waves: its duration is one wave's latency whatever the class count (float32: 10 us at
   // m <= 16, 20 at 17, 32-37 at 20-24, 45 / 76 at 32 / 33, 0.28 / 0.40 ms at 48 / 64), while what it saves is a share of the
   // pair kernel (m=16 8 %, 17 6 %, 20-24 3 %, 32-64 9-10 %; m=12 2 %).  Launches with fewer pairs (per shard) than this

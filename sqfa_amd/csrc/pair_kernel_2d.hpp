@@ -56,7 +56,7 @@ struct PairCfg2D {
   // half sweep saved -- so that row keeps triangular factors)
   static constexpr int FACTOR_SWEEPS = SQFA_FACTOR_SWEEPS >= 0 ? SQFA_FACTOR_SWEEPS : ((sizeof(T) == 8 && MR_ >= 48) ? 0 : 2);
   static constexpr bool DENSE_FACTOR = FACTOR_SWEEPS > 0;
-  static constexpr bool MEAN_METRIC = SQFA_FACTOR_MEAN && DENSE_FACTOR && MR_ <= 33;   // as PairCfg::MEAN_METRIC
+  static constexpr bool MEAN_METRIC = SQFA_FACTOR_MEAN && DENSE_FACTOR && (MR_ <= 17 || MR_ == 32);   // as PairCfg::MEAN_METRIC
   static constexpr long FACTOR_MIN_PAIRS_F32 = MR_ <= 33 ? 45000 : (MR_ <= 48 ? 40000 : 25000);
   static constexpr long FACTOR_MIN_PAIRS = sizeof(T) == 4 ? FACTOR_MIN_PAIRS_F32 : FACTOR_MIN_PAIRS_F32 * 2 / 5;
   static constexpr bool PACK_LINV = MR_ >= 32;

@@ -804,7 +804,7 @@ static int pairwise_impl(const void* A, int nA, const void* B, int nB, int m, in
   // mean-metric factor pass (class_factor_mean_kernel): will K0b run, and on a size that has it?  Same rule as
   // launch_class_factors (the decision depends on (nA, nB, shard count, options) only: every shard of a job decides alike).
   const long pairs_per_shard = pair_count(nA, nB, shard_count);
-  const bool want_mean = g.mean_metric && mean_mode >= 0 && factor_mode >= 0 &&
+  const bool want_mean = g.mean_metric && mean_mode > 0 && factor_mode >= 0 &&
                          (factor_mode > 0 || pairs_per_shard >= g.factor_min_pairs) && nA >= 2;
   double* mean_parts = reinterpret_cast<double*>(ws + w.off_mean);
   double* mean_linv = mean_parts + (size_t)kMeanParts * g.MR * g.MR;

@@ -134,8 +134,12 @@ class SecondMomentsSQFA(nn.Module):
 
     # hooks used by the fitting loop ------------------------------------------------------
     def _prepare_statistics(self, data_statistics):
-        # a dict is reduced to second moments once instead of inside every closure
-        return _stats_to_scatter(data_statistics)
+        # a dict is reduced to second moments once instead of inside every closure; symmetric float32 GPU
+        # statistics of many classes are also packed once into their lower block triangle: every closure then streams
+        # ~52 % of the bytes (sqfa_project_scatters_packed; _native.prepare_packed decides and keeps the packed copy)
+        scatters = _stats_to_scatter(data_statistics)
+        _native.prepare_packed(scatters, self.filters.shape[0])
+        return scatters
 
     def _fused_input(self, prepared):
         return self._feature_scatters(prepared, True)
@@ -346,6 +350,7 @@ class SQFA(SecondMomentsSQFA):
     def _prepare_statistics(self, data_statistics):
         if not isinstance(data_statistics, dict):
             raise TypeError("data_statistics must be a dictionary with 'means' and 'covariances' keys.")
+        _native.prepare_packed(data_statistics["covariances"], self.filters.shape[0])   # see SecondMomentsSQFA._prepare_statistics
         return data_statistics
 
     def _fused_input(self, prepared):

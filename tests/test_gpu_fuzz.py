@@ -47,6 +47,22 @@ def test_random_case_through_class_factor_pass(class_factors_always, m, nA, nB, 
 
 
 @pytest.fixture
+def mean_metric_factors():
+    """The opt-in variant of the factor pass (sqfa_airm_options::mean_metric_policy = 1: columns orthogonalised in the metric
+    of the mean class, class_factor_mean_kernel), forced on together with the pass itself."""
+    from sqfa_amd import _native
+    with _native.policies(class_factor=1, mean_metric=1):
+        yield
+
+
+@pytest.mark.parametrize("m,nA,nB,sqrt_mode,weighted,shards,f64", [c for c in CASES if 9 <= c[0] <= 17 or 25 <= c[0] <= 32])
+def test_random_case_through_mean_metric_factor_pass(mean_metric_factors, m, nA, nB, sqrt_mode, weighted, shards, f64):
+    """The same sweep through the mean-metric factor pass (sizes that have it): ragged counts, cross mode (the mean is that
+    of the A side), identity-padded sizes, shards (every shard forms the same mean)."""
+    test_random_case(m, nA, nB, sqrt_mode, weighted, shards, f64)
+
+
+@pytest.fixture
 def regular_rows_only():
     """Keep small launches on the regular lane geometries: by default these cases (a few hundred pairs) run on the
     small-launch rows of configs.hpp wherever one exists (sqfa_airm_options::geometry_policy, include/sqfa_hip.h)."""
@@ -218,6 +234,32 @@ def test_class_factor_pass_on_and_off_agree(m, f64):
     assert abs(on["loss"].item() - off["loss"].item()) <= ltol * abs(off["loss"].item())
     assert rel_err(on["gradA"].cpu(), off["gradA"].cpu().numpy()) <= gtol
     assert not torch.equal(on["gradA"], off["gradA"])  # the pass did run (a different factor rounds differently)
+
+
+@pytest.mark.parametrize("m,f64", [(12, False), (16, False), (17, False), (32, False), (16, True), (17, True), (29, True)])
+def test_mean_metric_factor_pass_on_and_off_agree(m, f64):
+    """The mean-metric pass hands K1 L_i V with another orthogonal V: still a factor of the same matrix, so the result
+    may only move by rounding -- also for classes that share an ill-conditioned mean (where it changes the factors most)."""
+    from sqfa_amd import _native
+    g = torch.Generator().manual_seed(3 * m)
+    C = 40
+    dtype = torch.float64 if f64 else torch.float32
+    q, _ = torch.linalg.qr(torch.randn(m, m, generator=g, dtype=torch.float64))
+    root = (q * torch.logspace(0, 1.5, m, dtype=torch.float64)) @ q.T             # cond(Sbar) = 1e3
+    E = torch.randn(C, m, m, generator=g, dtype=torch.float64) * 0.3 / m ** 0.5
+    M = torch.eye(m, dtype=torch.float64) + 0.5 * (E + E.transpose(1, 2))
+    A = (root @ (M @ M.transpose(1, 2)) @ root).to(dtype).to(DEV)
+    outs = {}
+    for mode in (0, 1):
+        with _native.policies(class_factor=1, mean_metric=mode):
+            outs[mode] = _native.hip_pair_backend(A, None, scale=1.0, eps=1e-6, sqrt_mode=True, weights=None, uniform_weight=1.0,
+                                                  shard=(0, 1), want_loss=True, want_grad=True, want_dist=True, want_eig=False)
+    off, on = outs[0], outs[1]
+    assert on["nonfinite"].tolist() == [0, 0]
+    ltol, gtol = (1e-12, 1e-9) if f64 else (1e-6, 3e-5)                              # gradients of cond-1e3 classes: cond * eps
+    assert abs(on["loss"].item() - off["loss"].item()) <= ltol * abs(off["loss"].item())
+    assert rel_err(on["gradA"].cpu(), off["gradA"].cpu().numpy()) <= gtol
+    assert not torch.equal(on["gradA"], off["gradA"])  # the other pass did run
 
 
 @pytest.mark.parametrize("m", [16, 17, 33])

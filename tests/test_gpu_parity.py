@@ -435,12 +435,16 @@ def test_transform_scatters_nonsymmetric_input_takes_general_path():
     assert _native.native_projection_supported(sym, model.filters)
 
 
+@pytest.mark.parametrize("packed", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("C,D,K", [(3, 784, 16), (2, 2048, 32), (4, 132, 8)])
-def test_transform_scatters_vs_reference_golden(C, D, K, dtype):
+def test_transform_scatters_vs_reference_golden(C, D, K, dtype, packed, monkeypatch):
     """transform_scatters / transform through the streaming projection kernels against the REFERENCE's
     outputs (golden G3b: src/sqfa/model.py:172-237 evaluated by importing the reference) at the c3 / c4
-    shapes: values and the gradient of a weighted sum with respect to the raw filter parameter."""
+    shapes: values and the gradient of a weighted sum with respect to the raw filter parameter.
+    packed=True: the same through the block-triangular packed statistics (sqfa_project_scatters_packed)."""
+    if packed and (dtype != torch.float32 or D % 16):
+        pytest.skip("the packed projection is float32, D % 16 == 0")
     import model_cases as mc
     import sqfa_amd
     from sqfa_amd import _native
@@ -455,6 +459,12 @@ def test_transform_scatters_vs_reference_golden(C, D, K, dtype):
     with torch.no_grad():
         model.parametrizations.filters.original.copy_(torch.tensor(G3B[f"{key}_raw"], dtype=dtype))
     assert _native.native_projection_supported(cov, model.filters)
+    if packed:
+        monkeypatch.setattr(_native, "PACKED_MIN_CLASSES", 1)
+        monkeypatch.setattr(_native, "PACKED_MAX_FILTERS", 64)
+        assert _native.prepare_packed(cov, K) is not None and _native.packed_for(cov, K) is not None
+    else:
+        assert _native.packed_for(cov) is None
     S = model.transform_scatters(cov)
     Z = model.transform(stats["means"].to(dtype).to(DEV))
     f64 = dtype == torch.float64

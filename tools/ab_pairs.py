@@ -41,7 +41,7 @@ for rnd in range(5):
     ks.append(ms.value / max(n.value, 1)); es.append(a.elapsed_time(b) / reps)
 m = S.shape[1]
 k = statistics.median(ks)
-print(f"m={m} {str(dtype)[6:]} kernel {k:.4f} ms (min {min(ks):.4f})  eval {statistics.median(es):.4f} ms  nominal {8*C*(C-1)*m**3/k/1e9/157.3e3:.3f}  "
+print(f"m={m} {str(dtype)[6:]} kernel {k:.4f} ms (min {min(ks):.4f})  eval {statistics.median(es):.4f} ms  nominal {8*C*(C-1)*m**3/k/1e9/157.3:.3f}  "
       f"sweeps {c[0]/max(c[1],1):.2f}  loss {out['loss'].item():.7f} flags {out['nonfinite'].tolist()}")
 '''
 

@@ -15,7 +15,7 @@ lib = _lib.load()
 
 
 def kernel_us(S, scale, mode, reps=20):
-    lib.sqfa_airm_geometry_policy(mode)
+    _native.POLICY["geometry"] = mode
     P = S.shape[0] * (S.shape[0] - 1) // 2
     f = lambda: _native.hip_pair_backend(S, None, scale=scale, eps=1e-6, sqrt_mode=True, weights=None, uniform_weight=-1.0 / P,
                                          shard=(0, 1), want_loss=True, want_grad=True, want_dist=False, want_eig=False)
@@ -29,12 +29,14 @@ def kernel_us(S, scale, mode, reps=20):
     ms, n = ctypes.c_double(), ctypes.c_int()
     lib.sqfa_airm_profile_read(ctypes.byref(ms), ctypes.byref(n))
     lib.sqfa_airm_profile(0)
-    lib.sqfa_airm_geometry_policy(0)
+    _native.POLICY["geometry"] = 0
     return ms.value / n.value * 1e3
 
 
-for K, model in ((4, "sqfa"), (8, "smsqfa"), (8, "sqfa"), (16, "smsqfa"), (16, "sqfa")):
-    for C in (50, 100, 150, 200, 300, 450, 600):
-        S, scale = bench.make_feature_scatters(C, 784, K, model, torch.device("cuda"), torch.float32)
+DTYPE = torch.float64 if (len(sys.argv) > 1 and sys.argv[1] == "f64") else torch.float32
+CASES = ((8, "smsqfa"), (4, "sqfa")) if DTYPE == torch.float64 else ((4, "sqfa"), (8, "smsqfa"), (8, "sqfa"), (16, "smsqfa"), (16, "sqfa"))
+for K, model in CASES:
+    for C in (50, 100, 150, 200, 300, 450, 600, 800, 1000):
+        S, scale = bench.make_feature_scatters(C, 784, K, model, torch.device("cuda"), DTYPE)
         a, b = kernel_us(S, scale, -1), kernel_us(S, scale, 1)
         print(f"m={S.shape[1]:2d} C={C:4d} ({C*(C-1)//2:7d} pairs): regular row {a:8.1f} us, small-launch row {b:8.1f} us  -> {'small' if b < a else 'regular'}", flush=True)
