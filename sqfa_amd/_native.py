@@ -456,19 +456,22 @@ def native_projection_supported(scatters, filters):
 # The symmetric (C,D,D) statistics are packed ONCE per prepared tensor (model._prepare_statistics) into their lower block
 # triangle; every closure then streams 51-54 % of the bytes.  The packed copy lives beside the caller's tensor (which the
 # caller owns and may free: statistics.pack_scatters hands the packed form out for that case).
-# Measured (tools/time_projection_packed.py, profiles/r4_projection_packed.txt; full tensor -> packed): c3 (C=1000, D=784, K=16)
-# 0.449 -> 0.353 ms, K=8 0.437 -> 0.327, D=1024 0.626 -> 0.551, D=2048 / K=16 2.71 -> 2.29, D=3072 / K=16 (C=500) 2.97 -> 2.51;
-# K=32 (c4) 3.02 -> 4.41 ms (two filter blocks: twice the exact-f32 MFMA work per byte, MFMA-bound) and C=100 (c5: one workgroup
-# per class leaves 60 % of the CUs idle) 0.59 -> 1.22 ms keep the full-tensor kernel.
+# Measured (tools/time_projection_packed.py, profiles/r4_projection_packed.txt; full tensor -> packed, two boxes): c3 (C=1000,
+# D=784, K=16) 0.43-0.45 -> 0.35-0.37 ms, K=8 0.43 -> 0.33-0.35, D=1024 0.63-0.67 -> 0.55-0.58, D=2048 / K=16 2.70 -> 2.29-2.40;
+# it LOSES where the walk is short or the chip is not full: D=512 0.169 -> 0.186, C=256 0.121 -> 0.143, C=500 / D=3072 a tie;
+# K=32 (c4) 3.02 -> 4.4-4.6 ms (two filter blocks: twice the exact-f32 MFMA work per byte, MFMA-bound); C=100 (c5) 0.58 -> 1.1-1.2 ms
+# (one workgroup per class leaves 60 % of the CUs idle; splitting a class over several workgroups with a second pass over
+# their partial results was built and measured at 1.08 ms: the per-row-block barrier of the walk dominates there; removed).
 PACKED_PROJECTION = True
-PACKED_MIN_CLASSES = 256      # one workgroup per class: fewer classes than CUs leave the chip idle (c5: C=100 keeps the full kernel)
+PACKED_MIN_CLASSES = 512      # one workgroup per class, two resident per CU
+PACKED_MIN_DIM = 768
 PACKED_MAX_FILTERS = 16       # one 16-filter block: beyond it the packed kernel is MFMA-bound and loses to the full-tensor stream
 _packed_cache = {}            # id(scatters) -> (weakref, _version, packed tensor)
 
 
 def packed_supported(scatters):
     return (PACKED_PROJECTION and scatters.is_cuda and scatters.dtype == torch.float32 and scatters.dim() == 3
-            and scatters.shape[-1] == scatters.shape[-2] and scatters.shape[-1] % 16 == 0 and 64 <= scatters.shape[-1] <= 4096
+            and scatters.shape[-1] == scatters.shape[-2] and scatters.shape[-1] % 16 == 0 and PACKED_MIN_DIM <= scatters.shape[-1] <= 4096
             and scatters.shape[0] >= PACKED_MIN_CLASSES and scatters.is_contiguous() and scatters.data_ptr() % 16 == 0
             and not scatters.requires_grad)
 

@@ -98,6 +98,8 @@ def test_closure_on_packed_statistics_matches_full_tensor(model_name, monkeypatc
     model = cls(n_dim=D, n_filters=K, feature_noise=0.01).to(DEV)
     stats = {"means": mu, "covariances": cov}
     out = {}
+    monkeypatch.setattr(_native, "PACKED_MIN_CLASSES", 256)
+    monkeypatch.setattr(_native, "PACKED_MIN_DIM", 64)
     for use in (True, False):
         monkeypatch.setattr(_native, "PACKED_PROJECTION", use)
         prepared = model._prepare_statistics(stats)

@@ -461,6 +461,7 @@ def test_transform_scatters_vs_reference_golden(C, D, K, dtype, packed, monkeypa
     assert _native.native_projection_supported(cov, model.filters)
     if packed:
         monkeypatch.setattr(_native, "PACKED_MIN_CLASSES", 1)
+        monkeypatch.setattr(_native, "PACKED_MIN_DIM", 64)
         monkeypatch.setattr(_native, "PACKED_MAX_FILTERS", 64)
         assert _native.prepare_packed(cov, K) is not None and _native.packed_for(cov, K) is not None
     else:
