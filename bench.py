@@ -38,7 +38,7 @@ if ROOT not in sys.path:
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector == f32 MFMA dense peak
 FP64_PEAK_TFLOPS = 78.6    # MI355X public specification (FP64 vector = half the FP32 vector rate); the guide's table has no f64 row
 HBM_PEAK_GBS = 8000.0
-PMC_FILE = "r3_pmc_c3.json"   # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary the `traffic` fields quote
+PMC_FILE = "r4_pmc_c3.json"   # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary the `traffic` fields quote
 
 WORKLOADS = {
     # name: (C, D, K, model)   model: "smsqfa" -> m=K, "sqfa" -> m=K+1 (Calvo-Oller embedding, scale 1/2)
@@ -727,8 +727,7 @@ def main():
             result["scaling_c4_closure"] = c4_closure
         if not args.no_closure and world == 1 and dtype == torch.float32:
             result["closure"] = closure_benchmark(C, D, K, model, device, max(10, min(100, args.steps // 2)), lib, with_fit=args.fit)
-            if not result["closure"]["roofline"]["packed_statistics"]:   # the committed PMC summary is the full-tensor kernel's
-                result["closure"]["roofline"]["traffic"] = pmc_traffic("project_kernel", args.workload, args.dtype)
+            result["closure"]["roofline"]["traffic"] = pmc_traffic(result["closure"]["roofline"]["kernel"], args.workload, args.dtype)
             result["closure"]["roofline"]["traffic_unit"] = f"bytes per launch (profiles/{PMC_FILE})"
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(S_cpu, scale, C)
