@@ -459,14 +459,16 @@ def test_transform_scatters_vs_reference_golden(C, D, K, dtype, packed, monkeypa
     with torch.no_grad():
         model.parametrizations.filters.original.copy_(torch.tensor(G3B[f"{key}_raw"], dtype=dtype))
     assert _native.native_projection_supported(cov, model.filters)
+    used = []
+    real_packed_for = _native.packed_for
+    monkeypatch.setattr(_native, "packed_for", lambda sc, k=1: (lambda r: (used.append(r is not None), r)[1])(real_packed_for(sc, k)))
     if packed:
         monkeypatch.setattr(_native, "PACKED_MIN_CLASSES", 1)
         monkeypatch.setattr(_native, "PACKED_MIN_DIM", 64)
         monkeypatch.setattr(_native, "PACKED_MAX_FILTERS", 64)
-        assert _native.prepare_packed(cov, K) is not None and _native.packed_for(cov, K) is not None
-    else:
-        assert _native.packed_for(cov) is None
+        assert _native.prepare_packed(cov, K) is not None
     S = model.transform_scatters(cov)
+    assert used and used[-1] == packed        # which projection kernel the call went through
     Z = model.transform(stats["means"].to(dtype).to(DEV))
     f64 = dtype == torch.float64
     dev_S = rel_err(G3B[f"{key}_S_f32"], G3B[f"{key}_S_f64"])
