@@ -60,17 +60,27 @@
 #endif
 #ifndef SQFA_CONFIGS_F64_SMALL
 #define SQFA_CONFIGS_F64_SMALL(X) \
-  X(double, 8, 2, 4, 8, 4)
+  X(double, 8, 2, 4, 8, 4)   \
+  X(double, 16, 8, 2, 8, 4)  \
+  X(double, 17, 8, 3, 8, 4)
 #endif
 // crossovers measured with tools/time_small_launch.py (profiles/r3_small_launch.txt): m <= 8 the small row still wins at 180 k
 // pairs (64.5 vs 73.4 us) and loses at 500 k (176 vs 154); m=9...12 at ~15 k pairs; m=16 / 17 at ~20 k
 // m=20 (8 lanes x 3 slots) 118 -> 86 us at C=50, 121 -> 96 at C=100, 124 -> 110 at C=130, 156 -> 162 at C=200; m=32 (32 lanes x 1
 // slot) 235 -> 115, 249 -> 151, 293 -> 270, 489 -> 539; other candidates lost or gained < 15 % (m=4 4 x 1, m=24 16 x 2, m=33 16 x 3 / 32 x 2): no row
 constexpr long small_launch_max_pairs(int MR) { return MR <= 8 ? 250000 : (MR <= 12 ? 14000 : (MR <= 17 ? 20000 : 12000)); }
+// float64 crossovers (round 4, tools/time_small_launch.py f64, profiles/r4_small_launch_f64.txt; regular / small-launch row, us):
+//   m=8  (1 x 8 / 2 x 4):  C=100 39.5 / 30.5, C=200 45.1 / 34.3, C=300 48.5 / 52.0, C=450 106 / 89, C=600 140 / 128, C=800 210 / 215
+//   m=16 (4 x 4 / 8 x 2):  C=100 101 / 74, C=200 160 / 139, C=300 236 / 265, C=450 510 / 478, C=600 824 / 822, C=800 1314 / 1454
+//   m=17 (4 x 5 / 8 x 3):  C=100 133 / 103, C=150 141 / 159, C=200 257 / 225, C=300 400 / 415, C=450 830 / 794, C=600 1393 / 1428
+// (wave-count quantisation makes the curves cross more than once: the thresholds sit where the small row stops winning clearly)
 #ifndef SQFA_SMALL_MAX_PAIRS_F64_8
-#define SQFA_SMALL_MAX_PAIRS_F64_8 120000
+#define SQFA_SMALL_MAX_PAIRS_F64_8 250000
 #endif
-constexpr long small_launch_max_pairs_f64(int MR) { return SQFA_SMALL_MAX_PAIRS_F64_8; }
+#ifndef SQFA_SMALL_MAX_PAIRS_F64_16
+#define SQFA_SMALL_MAX_PAIRS_F64_16 30000
+#endif
+constexpr long small_launch_max_pairs_f64(int MR) { return MR <= 8 ? SQFA_SMALL_MAX_PAIRS_F64_8 : SQFA_SMALL_MAX_PAIRS_F64_16; }
 
 #define SQFA_CONFIGS_F32(X) \
   SQFA_ROW_F32_4(X) \
@@ -96,11 +106,13 @@ constexpr long small_launch_max_pairs_f64(int MR) { return SQFA_SMALL_MAX_PAIRS_
 #ifndef SQFA_ROW_F64_12
 #define SQFA_ROW_F64_12(X) X(double, 12, 4, 3, 8, 4)
 #endif
+// round 4: 4-lane groups with every partner row through DPP (no ds_swizzle: see swizzled_rows_of_8) -- m=16 2.13 -> 1.92 ms,
+// m=17 3.67 -> 3.53 ms at C=1000; the 8-lane rows of round 3 stay as small-launch rows
 #ifndef SQFA_ROW_F64_16
-#define SQFA_ROW_F64_16(X) X(double, 16, 8, 2, 8, 4)
+#define SQFA_ROW_F64_16(X) X(double, 16, 4, 4, 8, 4)
 #endif
 #ifndef SQFA_ROW_F64_17
-#define SQFA_ROW_F64_17(X) X(double, 17, 8, 3, 8, 4)
+#define SQFA_ROW_F64_17(X) X(double, 17, 4, 5, 8, 4)
 #endif
 #ifndef SQFA_ROW_F64_20
 #define SQFA_ROW_F64_20(X) X(double, 20, 8, 3, 8, 4)

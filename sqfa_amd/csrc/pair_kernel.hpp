@@ -217,7 +217,10 @@ template <typename T, int G, int MR> constexpr int swizzled_rows_of_8() {
   // crossbar is the tighter pipe again and half of the rows go back to DPP (round 2, alternating runs on one
   // box: m=16 1.098 -> 1.066 ms, m=17 1.647 -> 1.588); the unpaired m=12 keeps all rows on the crossbar
   // (0.574 vs 0.586 ms)
-  if (G <= 4) return (sizeof(T) == 4 && MR >= 16) ? 4 : 8;
+  // float64 4-lane groups: NO rows through the crossbar (round 4; a 64-bit element is two ds_swizzle operations and the
+  // crossbar became the tighter pipe: m=16 4 x 4 2.09 ms with all rows swizzled, 1.98 with half, 1.92 with none; m=12
+  // 0.959 -> 0.886; m=17 4 x 5 3.79 -> 3.53 -- profiles/r4_pairs_fewer_lanes.txt)
+  if (G <= 4) return sizeof(T) == 8 ? 0 : (MR >= 16 ? 4 : 8);
   return sizeof(T) == 4 ? 1 : 0;
 }
 template <int S, int SWZ, typename T> __device__ __forceinline__ T lane_xor_row(T v, int s, int r) {
@@ -812,7 +815,7 @@ struct PairCfg {
   // float64 16-lane groups with their 15 rounds unrolled: m=32 (128 registers of state) needs the whole file
   // (1261 spilled VGPRs at two waves per SIMD), m=24 (96) fits two waves
 #ifndef SQFA_F64_TWO_WAVE_XREGS
-#define SQFA_F64_TWO_WAVE_XREGS 140
+#define SQFA_F64_TWO_WAVE_XREGS 180  // 140 until round 4: m=17 as 4 x 5 (170 registers of state) runs at two waves per SIMD
 #endif
   static constexpr int F64_TWO_WAVE_XREGS = G_ >= 16 ? 100 : SQFA_F64_TWO_WAVE_XREGS;
   static constexpr int MIN_WAVES = sizeof(T) == 8 ? (XREGS <= 64 ? SQFA_F64_SMALL_WAVES : (XREGS <= F64_TWO_WAVE_XREGS ? 2 : 1))

@@ -34,7 +34,7 @@ def kernel_us(S, scale, mode, reps=20):
 
 
 DTYPE = torch.float64 if (len(sys.argv) > 1 and sys.argv[1] == "f64") else torch.float32
-CASES = ((8, "smsqfa"), (4, "sqfa")) if DTYPE == torch.float64 else ((4, "sqfa"), (8, "smsqfa"), (8, "sqfa"), (16, "smsqfa"), (16, "sqfa"))
+CASES = ((8, "smsqfa"), (16, "smsqfa"), (16, "sqfa")) if DTYPE == torch.float64 else ((4, "sqfa"), (8, "smsqfa"), (8, "sqfa"), (16, "smsqfa"), (16, "sqfa"))
 for K, model in CASES:
     for C in (50, 100, 150, 200, 300, 450, 600, 800, 1000):
         S, scale = bench.make_feature_scatters(C, 784, K, model, torch.device("cuda"), DTYPE)
