@@ -187,8 +187,11 @@ template <int S> __device__ __forceinline__ double swizzle_xor(double v) {
 // value held by lane (lane ^ S).  S > 0: compile-time partner -- DPP quad_perm for S <= 3,
 // ds_swizzle (LDS crossbar, bit-mask mode) for 4 <= S < 32; S == 0: runtime partner `s`
 // through ds_bpermute (3x slower than ds_swizzle, tools/ubench/swizzle_rate.hip).
+// bit S set: partner lane^S (S = 7, 8, 15) through a DPP row move instead of the crossbar.  Round 4: bit 7 (row_half_mirror) on --
+// the 8-lane groups reach partners 4..7 through ds_swizzle only, and taking one of the four off the crossbar measured m=24
+// 2.937 -> 2.890 ms, m=32 7.66-7.69 -> 7.53, m=33 10.34 -> 10.19 (C=1000, profiles/r4_pairs_fewer_lanes.txt, last section)
 #ifndef SQFA_DPP_S_MASK
-#define SQFA_DPP_S_MASK 0  // bit S set: partner lane^S (S = 7, 8, 15) through a DPP row move instead of the crossbar
+#define SQFA_DPP_S_MASK 0x80
 #endif
 template <int S, typename T> __device__ __forceinline__ T lane_xor(T v, int s) {
   if constexpr (S == 1) return dpp_mov<0xB1>(v);

@@ -26,7 +26,9 @@ done
 objs="$objs $out/obj_$name/sqfa_api.o"
 wait
 for o in build/*.o; do
-  [ "$(basename $o)" = "sqfa_api.o" ] || objs="$objs $o"
+  b=$(basename $o)
+  # the regular build's copy of an object that this variant rebuilt (sqfa_api.o, the listed 2-D rows) is left out
+  [ "$b" = "sqfa_api.o" ] || [ -f "$out/obj_$name/$b" ] || objs="$objs $o"
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/$name.so $objs
 echo "built $out/$name.so"
