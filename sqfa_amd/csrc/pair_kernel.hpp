@@ -190,8 +190,10 @@ template <int S> __device__ __forceinline__ double swizzle_xor(double v) {
 // bit S set: partner lane^S (S = 7, 8, 15) through a DPP row move instead of the crossbar.  Round 4: bit 7 (row_half_mirror) on --
 // the 8-lane groups reach partners 4..7 through ds_swizzle only, and taking one of the four off the crossbar measured m=24
 // 2.937 -> 2.890 ms, m=32 7.66-7.69 -> 7.53, m=33 10.34 -> 10.19 (C=1000, profiles/r4_pairs_fewer_lanes.txt, last section)
+// Bits 8 and 15 (row_ror:8, row_mirror: the 16- and 32-lane groups) on as well: float64 m=32 / 33 / 48 (2-D rows) -1.6 / -1.1 /
+// -2.7 %, float32 m=48 / 64 -2.4 / -1.0 %, nothing moves at m <= 33 float32 (same file, "bits 7, 8, 15").
 #ifndef SQFA_DPP_S_MASK
-#define SQFA_DPP_S_MASK 0x80
+#define SQFA_DPP_S_MASK 0x8180
 #endif
 template <int S, typename T> __device__ __forceinline__ T lane_xor(T v, int s) {
   if constexpr (S == 1) return dpp_mov<0xB1>(v);
