@@ -113,3 +113,14 @@ def test_closure_on_packed_statistics_matches_full_tensor(model_name, monkeypatc
     assert abs(out[True][0] - out[False][0]) <= 1e-6 * abs(out[False][0])
     assert rel_err(out[True][1].cpu(), out[False][1].cpu().numpy()) <= 1e-5
     assert not torch.equal(out[True][1], out[False][1])               # the packed kernel did run
+
+
+_prng = np.random.default_rng(2024)
+RANDOM_SHAPES = [(int(_prng.integers(1, 7)), 16 * int(_prng.integers(1, 41)), int(_prng.integers(1, 65))) for _ in range(16)]
+
+
+@pytest.mark.parametrize("C,D,K", [(c, d, min(k, d)) for c, d, k in RANDOM_SHAPES])
+def test_packed_projection_random_shapes(C, D, K):
+    """Seeded random (C, D, K) with D % 16 == 0: every stripe count / filter-block count / ragged last stripe the launcher's
+    workgroup table can be asked for, against the float64 expression."""
+    test_packed_projection_vs_float64_expression(C, D, K)

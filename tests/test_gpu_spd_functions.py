@@ -119,3 +119,14 @@ def test_log_euclidean_runs_on_the_native_eigensolver(no_library_eigh):
     assert rel_err(D[:40, :40].detach().cpu(), ref.numpy()) <= 1e-5
     distances.log_euclidean(S, S).sum().backward()
     assert torch.isfinite(S.grad).all()
+
+
+_prng = np.random.default_rng(77)
+RANDOM_SIZES = [(int(_prng.integers(1, 71)), int(_prng.integers(1, 65))) for _ in range(12)]
+
+
+@pytest.mark.parametrize("n,m", RANDOM_SIZES)
+def test_spd_log_random_sizes(no_library_eigh, n, m):
+    """Seeded random (n, m <= 64): ragged class counts against every padded size / lane geometry of the per-class eigensolver."""
+    test_values_and_gradients_vs_reference_expression(None, n, m, "spd_log", torch.float64)
+    test_values_and_gradients_vs_reference_expression(None, n, m, "spd_sqrt", torch.float32)
