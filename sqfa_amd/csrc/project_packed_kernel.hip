@@ -64,9 +64,8 @@ __global__ __launch_bounds__(256) void pack_scatters_kernel(const float* __restr
   *reinterpret_cast<float4*>(out + (size_t)c * class_elems + v * 4) = o;
 }
 
-#ifndef SQFA_PK_MIN_WAVES
-#define SQFA_PK_MIN_WAVES 0   // 0: by workgroup size
-#endif
+// (SQFA_PK_NO_ROWOUT / _NO_BARRIER / _NO_REDUCE / _FAKE_F / _FAKE_TR below are development switches for timing ablations --
+// profiles/r4_projection_packed.txt; results are wrong with any of them)
 template <int NB, int WAVES, int SPW, int MINW>
 __global__ __launch_bounds__(64 * WAVES, MINW) void project_packed_kernel(const float* __restrict__ F, const float* __restrict__ Pk,
                                                                     float* __restrict__ Tout, int D, int K, size_t class_elems) {
