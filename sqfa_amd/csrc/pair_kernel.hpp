@@ -306,7 +306,9 @@ __device__ __forceinline__ double wave_uniform(double v) {
 // breaks that tie antisymmetrically.  Outputs are the identity (u = ru = 1, k = 0) when the
 // columns are already orthogonal to working precision.
 // `MR` (the rows a column has in the calling layout) only selects the stop threshold: Real<T>::early2<MR>()
-template <typename T, int MR>
+// LOCAL: both columns are in this lane (one owner): no tie to break -- dh = +0 for equal norms, whose sign bit is the +1 a
+// lone owner would pick anyway (two instructions less per rotation)
+template <typename T, int MR, bool LOCAL = false>
 __device__ __forceinline__ void rot_scaled(T no, T nr, T gh, T Dx, T Dy, T tol2, T tie, T& u, T& ru, T& k, T& g2,
                                            bool& big) {
   using R = Real<T>;
@@ -318,7 +320,7 @@ __device__ __forceinline__ void rot_scaled(T no, T nr, T gh, T Dx, T Dy, T tol2,
   const T rh = R::rsq(R::fma_(dh, dh, g2));
   const T uu = R::fma_(T(0.5) * R::abs_(dh), rh, T(0.5));
   const T ruu = R::rcp(uu);
-  const T sgn = dh == T(0) ? tie : dh;
+  const T sgn = LOCAL ? dh : (dh == T(0) ? tie : dh);
   u = rot ? uu : T(1);
   ru = rot ? ruu : T(1);
   k = rot ? R::copysign_(T(0.5) * rh * ruu, sgn) : T(0);
@@ -624,7 +626,7 @@ __device__ __forceinline__ void local_step2(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
     T u, ru, k, g2;
-    rot_scaled<T, MR>(nrm[ca[q]], nrm[cb[q]], gh[q], D[ca[q]], D[cb[q]], tol2, T(1), u, ru, k, g2, big);
+    rot_scaled<T, MR, true>(nrm[ca[q]], nrm[cb[q]], gh[q], D[ca[q]], D[cb[q]], tol2, T(1), u, ru, k, g2, big);
     const T kgh = k * gh[q], kg2 = k * g2;
     a1[q] = -(kgh * D[cb[q]]);
     a2[q] = kgh * D[ca[q]];
@@ -687,6 +689,176 @@ __device__ __forceinline__ void z_visits(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[
     nrm[Z] = lane_xor<BIT>(nrm[Z], BIT);
     D[Z] = lane_xor<BIT>(D[Z], BIT);
     z_visits<T, MR, G, CPL, SWZ, V + 1, RS>(x, nrm, D, tol2, big);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Slot-exchange ordering of a sweep (round 4).  In the tournament above the columns never move: a rotation between
+// columns of different lanes is evaluated by BOTH owners, each fetching the partner's column (MR cross-lane moves per
+// rotated column, 2 MR per rotation) -- at 4 lanes x 4 slots 96 of the 120 rotations of a sweep are of that kind and the
+// moves are a quarter of all vector instructions.  Here the COLUMNS travel instead: slot s of every lane is exchanged
+// with the same slot of lane ^ mask (one in-place cross-lane move per element, nothing else), after which the
+// rotations between DIFFERENT slots are local to a lane -- no fetch, no second owner, no parameters to pass on.
+//
+// Which exchanges: write the lane index l and a phase counter k as elements of GF(2^g), G = 2^g lanes per group, and
+// give slot s the multiplier mu_s = s (as a field element; slot 0 never moves).  In phase k the column dealt to
+// (l, s) sits in lane l + mu_s k.  Columns (l, s), (l', s') with s != s' share a lane iff (mu_s + mu_s') k = l + l',
+// and since mu_s + mu_s' != 0 that happens in exactly ONE of the G phases: every such pair is local exactly once per
+// sweep.  Going from phase k to k + d moves slot s by the lane mask mu_s d; the phases are visited along the cyclic
+// reflected Gray code (d = 1, 2, 1, 4, ..., closing with G/2), so the G-th exchange brings every column home and a
+// sweep is G x [exchange the slots 1..CE-1, rotate all CE (CE-1) / 2 slot pairs locally].  Columns of the SAME slot
+// are always in different lanes: those G (G-1) / 2 pairs per slot keep the two-owner form (the t = 0 steps of the
+// tournament, one fetch and one update per owner).  Per lane and sweep at 4 x 4: 24 MR moves instead of 48 MR, the
+// same 96 MR fmas; at 8 x 4: 52 MR instead of 112 MR.  Needs 2 <= CE <= G slots (CE: the slots of the tournament).
+#ifndef SQFA_SLOT_EXCHANGE
+#define SQFA_SLOT_EXCHANGE 1
+#endif
+#ifndef SQFA_SLOT_EXCHANGE_MAX_G
+#define SQFA_SLOT_EXCHANGE_MAX_G 16
+#endif
+__host__ __device__ constexpr int gf2_mul(int a, int b, int g) {
+  const int poly = g == 1 ? 0x3 : (g == 2 ? 0x7 : (g == 3 ? 0xB : (g == 4 ? 0x13 : 0x25)));  // x+1, x^2+x+1, x^3+x+1, x^4+x+1, x^5+x^2+1
+  int p = 0;
+  for (int i = 0; i < g; ++i)
+    if ((b >> i) & 1) p ^= a << i;
+  for (int i = 2 * g - 2; i >= g; --i)
+    if ((p >> i) & 1) p ^= poly << (i - g);
+  return p;
+}
+template <int G, int CE> constexpr bool slot_exchange_ok() {  // CE: the slots that take part in the tournament
+  return SQFA_SLOT_EXCHANGE && G >= 2 && G <= SQFA_SLOT_EXCHANGE_MAX_G && CE >= 2 && CE <= G;
+}
+template <int G, int MR, int CPL> constexpr bool slot_exchange_cfg() {
+  return slot_exchange_ok<G, (z_visits_cfg<G, MR, CPL>() ? CPL - 1 : CPL)>();
+}
+// exchange slots S_..CE-1 for the phase step DELTA
+template <typename T, int MR, int G, int CPL, int CE, int SWZ, int DELTA, int S_ = 1>
+__device__ __forceinline__ void exchange_slots(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL]) {
+  if constexpr (S_ < CE) {
+    constexpr int M = gf2_mul(S_, DELTA, ilog2(G));
+    static_assert(M > 0 && M < G, "exchange partner outside the lane group");
+#pragma unroll
+    for (int r = 0; r < MR; ++r) x[S_][r] = lane_xor_row<M, SWZ>(x[S_][r], M, r);
+    nrm[S_] = lane_xor<M>(nrm[S_], M);
+    D[S_] = lane_xor<M>(D[S_], M);
+    exchange_slots<T, MR, G, CPL, CE, SWZ, DELTA, S_ + 1>(x, nrm, D);
+  }
+}
+// all pairs among the slots 0..CE-1 of a lane, tournament order, two disjoint pairs at a time
+template <typename T, int MR, int CPL, int CE, int T_, int CSTART, int RS>
+__device__ __forceinline__ void slot_t_steps(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], T tol2, bool& big) {
+  constexpr auto valid = [](int c) constexpr { return c < CE && (c ^ T_) > c && (c ^ T_) < CE; };
+  constexpr int first = [&]() constexpr { int c = CSTART; while (c < CE && !valid(c)) ++c; return c; }();
+  if constexpr (first < CE) {
+    constexpr int second = [&]() constexpr { int c = first + 1; while (c < CE && !valid(c)) ++c; return c; }();
+    if constexpr (second < CE) {
+      local_step2<T, MR, CPL, first, first ^ T_, second, second ^ T_, RS>(x, nrm, D, tol2, big);
+      slot_t_steps<T, MR, CPL, CE, T_, second + 1, RS>(x, nrm, D, tol2, big);
+    } else {
+      local_step2<T, MR, CPL, first, first ^ T_, -1, -1, RS>(x, nrm, D, tol2, big);
+    }
+  }
+}
+template <typename T, int MR, int CPL, int CE, int T_, int RS>
+__device__ __forceinline__ void slot_rounds(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], T tol2, bool& big) {
+  if constexpr (T_ < pow2ceil(CE)) {
+    slot_t_steps<T, MR, CPL, CE, T_, 0, RS>(x, nrm, D, tol2, big);
+    slot_rounds<T, MR, CPL, CE, T_ + 1, RS>(x, nrm, D, tol2, big);
+  }
+}
+template <typename T, int MR, int G, int CPL, int CE, int SWZ, int RS, int PH = 1>
+__device__ __forceinline__ void exchange_phases(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], T tol2, bool& big) {
+  if constexpr (PH <= G) {
+    constexpr int DELTA = PH == G ? G / 2 : (PH & -PH);
+    exchange_slots<T, MR, G, CPL, CE, SWZ, DELTA>(x, nrm, D);
+    slot_rounds<T, MR, CPL, CE, 1, RS>(x, nrm, D, tol2, big);
+    exchange_phases<T, MR, G, CPL, CE, SWZ, RS, PH + 1>(x, nrm, D, tol2, big);
+  }
+}
+// the same-slot pairs: the t = 0 steps of the tournament against every lane of the group
+template <typename T, int MR, int CPL, int S, int SWZ, bool LONE_LAST, int RS, int C>
+__device__ __forceinline__ void same_slot_single(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], T tol2, T tie, bool& big) {
+  if constexpr (C < tournament_slots<CPL, LONE_LAST>()) {
+    cross_step2<T, MR, CPL, S, SWZ, LONE_LAST, C, -1, 0, RS>(x, nrm, D, S, tol2, tie, big);
+    same_slot_single<T, MR, CPL, S, SWZ, LONE_LAST, RS, C + 1>(x, nrm, D, tol2, tie, big);
+  }
+}
+template <typename T, int MR, int G, int CPL, int SWZ, bool LONE_LAST, int RS, int S = 1>
+__device__ __forceinline__ void same_slot_rounds(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], T tol2, bool& big) {
+  if constexpr (S < G) {
+    const int lane_id = (int)(threadIdx.x & 63);
+    const T tie = ((lane_id ^ S) > lane_id) ? T(1) : T(-1);
+    if constexpr (paired_steps<T, G, MR>()) {
+      cross_t_steps<T, MR, CPL, S, SWZ, LONE_LAST, 0, 0, RS>(x, nrm, D, S, tol2, tie, big);
+    } else {
+      same_slot_single<T, MR, CPL, S, SWZ, LONE_LAST, RS, 0>(x, nrm, D, tol2, tie, big);
+    }
+    same_slot_rounds<T, MR, G, CPL, SWZ, LONE_LAST, RS, S + 1>(x, nrm, D, tol2, big);
+  }
+}
+// Square groups (4 lanes x 4 tournament slots: m = 16, 17): the same-slot pairs become local as well once the 4 x 4 block
+// (lane, slot) of every row is TRANSPOSED -- column (l, s) moves to lane s, slot l.  That is a lane-dependent choice of
+// registers, which costs selects on the VALU; through LDS it costs no vector instruction at all: per row, four 4-byte
+// writes at the transposed positions and one 16-byte read (the wave's own 1 KB scratch: the L_j^-1 staging area, idle
+// during the sweeps and reloaded for the back-transform; LDS operations of a wave execute in order, so consecutive rows
+// reuse the buffer without waiting).  A sweep is then G x [exchange, rotate locally] + transpose + rotate locally:
+// every rotation is local and evaluated once (30 per lane at 4 x 4 instead of 24 + 12 two-owner half steps).  The
+// layout alternates between the two orientations from sweep to sweep; an odd sweep count is undone by one more
+// transposition after the loop, so everything outside the sweeps sees the dealt positions.
+// Measured (C=1000, ms, two-owner same-slot steps -> transposition; profiles/r4_pairs_slot_exchange.txt): float32 m=16
+// 0.771 -> 0.753, float64 m=16 1.737 -> 1.678; but m=17 (three / two waves per SIMD and the lone column's serial visits on top)
+// 1.161 -> 1.210 and 3.08 -> 3.22 although the sweep is 11 % shorter in instructions: the wave sits out the LDS round trip
+// and nobody covers for it.  SQFA_SLOT_TRANSPOSE: 1 = full groups only (m = 16), 2 = also with a lone column
+#ifndef SQFA_SLOT_TRANSPOSE
+#define SQFA_SLOT_TRANSPOSE 1
+#endif
+template <int G, int MR, int CPL> constexpr bool slot_transpose_cfg() {
+  constexpr int CE = z_visits_cfg<G, MR, CPL>() ? CPL - 1 : CPL;
+  return SQFA_SLOT_TRANSPOSE && slot_exchange_cfg<G, MR, CPL>() && G == 4 && CE == 4 && (CE == CPL || SQFA_SLOT_TRANSPOSE >= 2);
+}
+constexpr int kTransposePitch = 72;
+constexpr int kTransposeElems = 3 * kTransposePitch + 64;  // elements of wave-private LDS `buf` must provide
+template <typename T, int MR, int CPL>
+__device__ __forceinline__ void transpose_slots(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], T* buf) {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));  // re-derived per call: not worth a register across the sweeps
+  const int lane = t & 63;
+  // slot s of the wave is written as one row of 64 lanes (row pitch kTransposePitch), lane (q, j) then reads the four lanes of
+  // its quad from row j: 16 aligned bytes.  Pitch 72 = 8 mod 32 banks: the writes of a row are consecutive, the 16-byte reads of
+  // eight neighbouring lanes fall into eight different 4-bank groups -- no conflicts on either side (pitch 64 serialises the
+  // reads four-fold, the (lane, slot)-major layout the writes)
+  T* wr = buf + lane;
+  const T* rd = buf + (lane & ~3) + kTransposePitch * (lane & 3);
+  auto pass = [&](T& v0, T& v1, T& v2, T& v3) {
+    wr[0] = v0;
+    wr[kTransposePitch] = v1;
+    wr[2 * kTransposePitch] = v2;
+    wr[3 * kTransposePitch] = v3;
+    if constexpr (sizeof(T) == 4) {
+      const float4 q = *reinterpret_cast<const float4*>(rd);
+      v0 = q.x; v1 = q.y; v2 = q.z; v3 = q.w;
+    } else {
+      const double2 q0 = *reinterpret_cast<const double2*>(rd), q1 = *reinterpret_cast<const double2*>(rd + 2);
+      v0 = q0.x; v1 = q0.y; v2 = q1.x; v3 = q1.y;
+    }
+  };
+#pragma unroll
+  for (int r = 0; r < MR; ++r) pass(x[0][r], x[1][r], x[2][r], x[3][r]);
+  pass(nrm[0], nrm[1], nrm[2], nrm[3]);
+  pass(D[0], D[1], D[2], D[3]);
+}
+
+// one sweep over the tournament slots (the lone column of the m = G (CPL-1) + 1 sizes still travels by z_visits)
+template <typename T, int MR, int G, int CPL, bool LONE_LAST, bool TRANSPOSE = false, int RS = 0>
+__device__ __forceinline__ void exchange_sweep(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], T tol2, bool& big, T* buf = nullptr) {
+  constexpr int CE = tournament_slots<CPL, LONE_LAST>();
+  constexpr int SWZ = swizzled_rows_of_8<T, G, MR>();
+  exchange_phases<T, MR, G, CPL, CE, SWZ, RS>(x, nrm, D, tol2, big);
+  if constexpr (TRANSPOSE) {
+    transpose_slots<T, MR, CPL>(x, nrm, D, buf);
+    slot_rounds<T, MR, CPL, CE, 1, RS>(x, nrm, D, tol2, big);
+  } else {
+    same_slot_rounds<T, MR, G, CPL, SWZ, LONE_LAST, RS>(x, nrm, D, tol2, big);
   }
 }
 
@@ -857,6 +1029,8 @@ struct PairCfg {
   static constexpr long FACTOR_MIN_PAIRS = sizeof(T) == 4 ? FACTOR_MIN_PAIRS_F32 : FACTOR_MIN_PAIRS_F32 * 2 / 5;
   static constexpr bool PACK_LINV = MR_ >= 32;
   static constexpr int LINV_ELEMS = PACK_LINV ? MR_ * (MR_ + 1) / 2 : MR_ * MR_;
+  // per-wave pitch of that staging area: it doubles as the scratch of transpose_slots
+  static constexpr int LI_PITCH = (slot_transpose_cfg<G_, MR_, CPL_>() && LINV_ELEMS < kTransposeElems) ? kTransposeElems : LINV_ELEMS;
   static_assert(G * CPL >= MR, "not enough column slots");
   static_assert(TJ % WAVES == 0, "TJ must be a multiple of the wave count");
   static_assert((TJ & (TJ - 1)) == 0, "TJ must be a power of two (run-time halving, shift-based tile search)");
@@ -876,7 +1050,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
   constexpr int WAVES = Cfg::WAVES, TRI = Cfg::TRI, TRIP = Cfg::TRIP, NT = Cfg::THREADS;
 
   __shared__ T s_ga[WAVES * TI * TRIP];  // per-wave private A-side accumulators (lower triangles)
-  __shared__ T s_li[WAVES * Cfg::LINV_ELEMS];  // L_j^-1 of the B class each wave is working on (layout: Cfg::PACK_LINV)
+  __shared__ T s_li[WAVES * Cfg::LI_PITCH];  // L_j^-1 of the B class each wave is working on (layout: Cfg::PACK_LINV)
   __shared__ T s_red[WAVES];
   __shared__ int s_redi[2 * WAVES];
 
@@ -959,7 +1133,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
     const int jc = __builtin_amdgcn_readfirstlane(j < p.nB ? j : p.nB - 1);
     constexpr int LE = Cfg::LINV_ELEMS;
     auto li_at = [](int r, int k) constexpr { return Cfg::PACK_LINV ? tri_index(r, k) : r * Cfg::MR + k; };
-    T* li = s_li + wave * LE;
+    T* li = s_li + wave * Cfg::LI_PITCH;
     {
       const T* __restrict__ src = LinvAll + (size_t)jc * LE;
       for (int k = lane; k < LE; k += 64) li[k] = src[k];
@@ -1032,6 +1206,10 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
         nrm[c] = a * D[c];
       }
       bool big = false;
+      if constexpr (slot_exchange_cfg<G, MR, CPL>()) {
+        // travelling columns, see exchange_slots / transpose_slots
+        exchange_sweep<T, MR, G, CPL, (MR == G * (CPL - 1) + 1), slot_transpose_cfg<G, MR, CPL>()>(x, nrm, D, tol2, big, li);
+      } else {
       // pairs inside my own lane
       if constexpr (SQFA_LOCAL_TOURNAMENT && G == 1) {  // measured: m=8 (one lane per pair) -4 %; no change for G >= 4
         local_rounds<T, MR, CPL, 1>(x, nrm, D, tol2, big);
@@ -1066,9 +1244,13 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
 #pragma unroll 1
         for (int s = 1; s < G; ++s) cross_round<T, MR, CPL, 0, 0, (MR == G * (CPL - 1) + 1)>(x, nrm, D, s, tol2, big);
       }
+      }
       if constexpr (z_visits_cfg<G, MR, CPL>()) z_visits<T, MR, G, CPL, swizzled_rows_of_8<T, G, MR>(), 0>(x, nrm, D, tol2, big);
       more = __any(big);
       ++sweeps;
+    }
+    if constexpr (slot_transpose_cfg<G, MR, CPL>()) {
+      if (sweeps & 1) transpose_slots<T, MR, CPL>(x, nrm, D, li);  // back to the dealt positions (wave-uniform branch)
     }
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
@@ -1077,6 +1259,10 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
       for (int r = 0; r < MR; ++r) x[c][r] *= dc;  // back to the true columns
     }
     lane = opaque_lane();
+    if constexpr (slot_transpose_cfg<G, MR, CPL>()) {  // the sweeps used the L_j^-1 staging area as scratch: stage it again
+      const T* __restrict__ src = LinvAll + (size_t)jc * LE;
+      for (int k = lane; k < LE; k += 64) li[k] = src[k];
+    }
     g = lane % G;
     i = i0 + lane / G;
     valid = (i < p.nA) && (j < p.nB) && (!p.self_mode || i > j);

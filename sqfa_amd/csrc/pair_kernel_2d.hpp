@@ -292,6 +292,9 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
       }
       bool big = false;
       constexpr int CE = (Cfg::LONE && SQFA_Z_VISITS) ? CPL - 1 : CPL;
+      if constexpr (slot_exchange_ok<GC, CE>()) {  // travelling columns (pair_kernel.hpp, exchange_slots)
+        exchange_sweep<T, MRL, GC, CPL, Cfg::LONE, false, RS>(x, nrm, D, tol2, big);
+      } else {
 #pragma unroll
       for (int c1 = 0; c1 < CE; ++c1) {
 #pragma unroll
@@ -314,6 +317,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
         }
       }
       if constexpr (GC > 1) cross_rounds_static<T, MRL, GC, CPL, 1, Cfg::LONE ? 1 : 0, RS>(x, nrm, D, tol2, big);
+      }
       if constexpr (Cfg::LONE && SQFA_Z_VISITS && GC > 1)
         z_visits<T, MRL, GC, CPL, swizzled_rows_of_8<T, GC, MRL>(), 0, RS>(x, nrm, D, tol2, big);
       more = __any(big);

@@ -46,6 +46,22 @@ __global__ void k(float* out, int iters, float seed) {
       REP16(asm volatile("v_mul_f32 %0, %0, %8\n v_fmac_f32 %0, %4, %9\n v_mul_f32 %1, %1, %8\n v_fmac_f32 %1, %5, %9\n"
                          "v_mul_f32 %2, %2, %8\n v_fmac_f32 %2, %6, %9\n v_mul_f32 %3, %3, %8\n v_fmac_f32 %3, %7, %9\n"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));)
+    } else if (KIND == 7) {  // v_permlane16_swap, 4 independent register pairs
+      REP16(asm volatile("v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n v_permlane16_swap_b32 %4, %5\n v_permlane16_swap_b32 %6, %7\n"
+                         "v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n v_permlane16_swap_b32 %4, %5\n v_permlane16_swap_b32 %6, %7\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+    } else if (KIND == 8) {  // v_permlane32_swap, 4 independent register pairs
+      REP16(asm volatile("v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n"
+                         "v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+    } else if (KIND == 9) {  // v_cndmask_b32 (vcc), 8 independent
+      REP16(asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                         "v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");)
+    } else if (KIND == 10) {  // 4 fma + 4 swaps interleaved (do the swaps hide behind arithmetic?)
+      REP16(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_permlane16_swap_b32 %4, %5\n v_fma_f32 %1, %1, %8, %9\n v_permlane16_swap_b32 %6, %7\n"
+                         "v_fma_f32 %2, %2, %8, %9\n v_permlane32_swap_b32 %4, %5\n v_fma_f32 %3, %3, %8, %9\n v_permlane32_swap_b32 %6, %7\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));)
     }
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
@@ -80,5 +96,9 @@ int main() {
   run<4>("v_rcp_f32 indep", 128);
   run<5>("v_pk_fma_f32 x4 indep", 128);
   run<6>("mul+fmac pairs", 128);
+  run<7>("v_permlane16_swap indep", 128);
+  run<8>("v_permlane32_swap indep", 128);
+  run<9>("v_cndmask_b32 indep", 128);
+  run<10>("fma + permlane swap 1:1", 128);
   return 0;
 }
