@@ -216,8 +216,13 @@ template <int S, typename T> __device__ __forceinline__ T lane_xor(T v, int s) {
 #ifndef SQFA_SWZ_ROWS_OF_8
 #define SQFA_SWZ_ROWS_OF_8 -1  // -1: by group size and element type
 #endif
-template <typename T, int G, int MR> constexpr int swizzled_rows_of_8() {
+template <typename T, int G, int MR, bool EXCHANGE = false> constexpr int swizzled_rows_of_8() {
   if (SQFA_SWZ_ROWS_OF_8 >= 0) return SQFA_SWZ_ROWS_OF_8;
+  // slot-exchange sweeps (round 4), float32 4-lane groups: ALL rows through the crossbar again -- half as many cross-lane moves
+  // as the tournament issued, and every DPP move is 1.63 issue slots of a kernel that is bound by them (C=1000: m=16
+  // 0.712 -> 0.692 ms with 8 of 8, 0.701 with 6, 0.732 with 2, 0.790 with none; m=17 1.142 -> 1.134; float64 keeps none:
+  // m=16 1.573 / 1.589 / 1.617 / 1.637 ms with 0 / 2 / 6 / 8; 8-lane groups +-0.5 %: unchanged)
+  if (EXCHANGE && G <= 4 && sizeof(T) == 4) return 8;
   // 4-lane groups: with two steps in flight and the fetch bursts at raised priority (float32, MR >= 16) the
   // crossbar is the tighter pipe again and half of the rows go back to DPP (round 2, alternating runs on one
   // box: m=16 1.098 -> 1.066 ms, m=17 1.647 -> 1.588); the unpaired m=12 keeps all rows on the crossbar
@@ -306,12 +311,13 @@ __device__ __forceinline__ double wave_uniform(double v) {
 // breaks that tie antisymmetrically.  Outputs are the identity (u = ru = 1, k = 0) when the
 // columns are already orthogonal to working precision.
 // `MR` (the rows a column has in the calling layout) only selects the stop threshold: Real<T>::early2<MR>()
-// LOCAL: both columns are in this lane (one owner): no tie to break -- dh = +0 for equal norms, whose sign bit is the +1 a
-// lone owner would pick anyway (two instructions less per rotation)
-template <typename T, int MR, bool LOCAL = false>
+template <typename T, int MR>
 __device__ __forceinline__ void rot_scaled(T no, T nr, T gh, T Dx, T Dy, T tol2, T tie, T& u, T& ru, T& k, T& g2,
                                            bool& big) {
   using R = Real<T>;
+#ifdef SQFA_ABL_NO_PARAMS  // development: timing ablation, wrong results
+  u = T(1); ru = T(1); k = gh * T(1e-3); g2 = gh * Dx; return;
+#endif
   const T ab = no * nr;
   g2 = gh * gh * (Dx * Dy);
   const bool rot = g2 > tol2 * ab;
@@ -320,10 +326,40 @@ __device__ __forceinline__ void rot_scaled(T no, T nr, T gh, T Dx, T Dy, T tol2,
   const T rh = R::rsq(R::fma_(dh, dh, g2));
   const T uu = R::fma_(T(0.5) * R::abs_(dh), rh, T(0.5));
   const T ruu = R::rcp(uu);
-  const T sgn = LOCAL ? dh : (dh == T(0) ? tie : dh);
+  const T sgn = dh == T(0) ? tie : dh;
   u = rot ? uu : T(1);
   ru = rot ? ruu : T(1);
   k = rot ? R::copysign_(T(0.5) * rh * ruu, sgn) : T(0);
+}
+
+// The same rotation for two columns of ONE lane (local_step2), written in d = nr - no and g4 = 4 g2 = (2 gh)^2 Dx Dy so that
+// no halving is left in the chain:  h4 = sqrt(d^2 + g4) = 2 h,  w = 1 + |d| / h4 = 2 u,  k/2 = 1 / (h4 w).  Returns u,
+// kgh = k gh (the caller's a1 = -kgh Dy, a2 = kgh Dx) and kg4 = (k/2) g4 = 2 k g2 (norm updates -+ kg4 / 2, folded into an
+// fma).  One owner: no tie to break (d = +0 for equal norms: the sign bit a lone owner would pick anyway), and the
+// "rotate at all" test is an absolute floor on g4 -- it only has to keep 0/0 out (zero and identity-padded columns have
+// g4 = 0 exactly); rotations below the rounding noise are harmless and cost the same as a skipped one.  24 instructions
+// instead of the 30 of rot_scaled + its caller; at 4 x 4 slots every rotation of a sweep is of this kind.
+template <typename T> struct RotFloor;
+template <> struct RotFloor<float> { static constexpr float v = 1.0e-32f; };
+template <> struct RotFloor<double> { static constexpr double v = 1.0e-290; };
+template <typename T, int MR>
+__device__ __forceinline__ void rot_local(T no, T nr, T gh, T Dx, T Dy, T& u, T& kgh, T& kg4, bool& big) {
+  using R = Real<T>;
+#ifdef SQFA_ABL_NO_PARAMS  // development: timing ablation, wrong results
+  u = T(1); kgh = gh * T(1e-3); kg4 = gh * Dx; return;
+#endif
+  const T e = gh + gh;
+  const T g4 = e * e * (Dx * Dy);
+  const bool rot = g4 > RotFloor<T>::v;
+  big = big || (g4 > (T(4) * R::template early2<MR>()) * (no * nr));
+  const T d = nr - no;
+  const T rh4 = R::rsq(R::fma_(d, d, g4));
+  const T w = R::fma_(R::abs_(d), rh4, T(1));
+  const T kp = R::copysign_(rh4 * R::rcp(w), d);
+  const T k = rot ? kp : T(0);
+  u = rot ? T(0.5) * w : T(1);
+  kgh = k * e;
+  kg4 = k * g4;
 }
 
 // Inner product of two register columns with NA independent partial sums (combined pairwise at the end): one
@@ -608,6 +644,10 @@ __device__ __forceinline__ void local_step2(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
   constexpr int NS = A1 >= 0 ? 2 : 1;
   constexpr int ca[2] = {A0, A1 >= 0 ? A1 : A0}, cb[2] = {B0, A1 >= 0 ? B1 : B0};
   T gh[2] = {T(0), T(0)};
+#ifdef SQFA_ABL_NO_DOT  // development: timing ablation, wrong results
+#pragma unroll
+  for (int q = 0; q < NS; ++q) gh[q] = x[ca[q]][0] * x[cb[q]][1];
+#else
   if constexpr (dot_accs<T, MR>() > 1) {
 #pragma unroll
     for (int q = 0; q < NS; ++q) gh[q] = dot_cols<T, MR>(x[ca[q]], x[cb[q]]);
@@ -618,6 +658,7 @@ __device__ __forceinline__ void local_step2(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
       for (int q = 0; q < NS; ++q) gh[q] = R::fma_(x[ca[q]][r], x[cb[q]][r], gh[q]);
     }
   }
+#endif
   if constexpr (RS != 0) {
 #pragma unroll
     for (int q = 0; q < NS; ++q) gh[q] = row_total<RS>(gh[q]);
@@ -625,18 +666,22 @@ __device__ __forceinline__ void local_step2(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
   T a1[2], a2[2];
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
-    T u, ru, k, g2;
-    rot_scaled<T, MR, true>(nrm[ca[q]], nrm[cb[q]], gh[q], D[ca[q]], D[cb[q]], tol2, T(1), u, ru, k, g2, big);
-    const T kgh = k * gh[q], kg2 = k * g2;
+    T u, kgh, kg4;
+    rot_local<T, MR>(nrm[ca[q]], nrm[cb[q]], gh[q], D[ca[q]], D[cb[q]], u, kgh, kg4, big);
     a1[q] = -(kgh * D[cb[q]]);
     a2[q] = kgh * D[ca[q]];
     D[ca[q]] *= u;
     D[cb[q]] *= u;
-    nrm[ca[q]] -= kg2;
-    nrm[cb[q]] += kg2;
+    nrm[ca[q]] = R::fma_(T(-0.5), kg4, nrm[ca[q]]);
+    nrm[cb[q]] = R::fma_(T(0.5), kg4, nrm[cb[q]]);
   }
+#ifdef SQFA_ABL_NO_UPDATE  // development: timing ablation, wrong results (two rows keep the parameters alive)
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+#else
 #pragma unroll
   for (int r = 0; r < MR; ++r) {
+#endif
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
       const T xp = x[ca[q]][r];
@@ -770,7 +815,9 @@ template <typename T, int MR, int G, int CPL, int CE, int SWZ, int RS, int PH = 
 __device__ __forceinline__ void exchange_phases(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], T tol2, bool& big) {
   if constexpr (PH <= G) {
     constexpr int DELTA = PH == G ? G / 2 : (PH & -PH);
+#ifndef SQFA_ABL_NO_EXCHANGE
     exchange_slots<T, MR, G, CPL, CE, SWZ, DELTA>(x, nrm, D);
+#endif
     slot_rounds<T, MR, CPL, CE, 1, RS>(x, nrm, D, tol2, big);
     exchange_phases<T, MR, G, CPL, CE, SWZ, RS, PH + 1>(x, nrm, D, tol2, big);
   }
@@ -852,10 +899,12 @@ __device__ __forceinline__ void transpose_slots(T (&x)[CPL][MR], T (&nrm)[CPL], 
 template <typename T, int MR, int G, int CPL, bool LONE_LAST, bool TRANSPOSE = false, int RS = 0>
 __device__ __forceinline__ void exchange_sweep(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], T tol2, bool& big, T* buf = nullptr) {
   constexpr int CE = tournament_slots<CPL, LONE_LAST>();
-  constexpr int SWZ = swizzled_rows_of_8<T, G, MR>();
+  constexpr int SWZ = swizzled_rows_of_8<T, G, MR, true>();
   exchange_phases<T, MR, G, CPL, CE, SWZ, RS>(x, nrm, D, tol2, big);
   if constexpr (TRANSPOSE) {
+#ifndef SQFA_ABL_NO_EXCHANGE
     transpose_slots<T, MR, CPL>(x, nrm, D, buf);
+#endif
     slot_rounds<T, MR, CPL, CE, 1, RS>(x, nrm, D, tol2, big);
   } else {
     same_slot_rounds<T, MR, G, CPL, SWZ, LONE_LAST, RS>(x, nrm, D, tol2, big);
@@ -1245,9 +1294,13 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
         for (int s = 1; s < G; ++s) cross_round<T, MR, CPL, 0, 0, (MR == G * (CPL - 1) + 1)>(x, nrm, D, s, tol2, big);
       }
       }
-      if constexpr (z_visits_cfg<G, MR, CPL>()) z_visits<T, MR, G, CPL, swizzled_rows_of_8<T, G, MR>(), 0>(x, nrm, D, tol2, big);
+      if constexpr (z_visits_cfg<G, MR, CPL>())
+        z_visits<T, MR, G, CPL, swizzled_rows_of_8<T, G, MR, slot_exchange_cfg<G, MR, CPL>()>(), 0>(x, nrm, D, tol2, big);
       more = __any(big);
       ++sweeps;
+#ifdef SQFA_ABL_FIXED_SWEEPS  // development: timing ablations run a fixed number of sweeps
+      more = sweeps < SQFA_ABL_FIXED_SWEEPS;
+#endif
     }
     if constexpr (slot_transpose_cfg<G, MR, CPL>()) {
       if (sweeps & 1) transpose_slots<T, MR, CPL>(x, nrm, D, li);  // back to the dealt positions (wave-uniform branch)
