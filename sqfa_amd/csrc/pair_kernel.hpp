@@ -859,10 +859,23 @@ __device__ __forceinline__ void same_slot_rounds(T (&x)[CPL][MR], T (&nrm)[CPL],
 #ifndef SQFA_SLOT_TRANSPOSE
 #define SQFA_SLOT_TRANSPOSE 1
 #endif
+// 8 lanes x 4 slots (m = 32): the same transposition inside every quad of lanes makes the same-slot pairs whose lanes differ
+// in the two low bits local; what is left -- lanes that differ in bit 2, same slot before, ANY slot pair after -- is one full
+// round of the two-owner tournament against lane ^ 4 (10 steps instead of the 16 of the 28 same-slot half steps it replaces).
+#ifndef SQFA_SLOT_TRANSPOSE_G8
+#define SQFA_SLOT_TRANSPOSE_G8 1
+#endif
+// (m=32 6.58 -> 6.29 ms, m=33 with its lone column 9.49 -> 9.14 ms at C=1000; the 4-lane group with a lone column, m=17,
+// loses as said above)
 template <int G, int MR, int CPL> constexpr bool slot_transpose_cfg() {
   constexpr int CE = z_visits_cfg<G, MR, CPL>() ? CPL - 1 : CPL;
-  return SQFA_SLOT_TRANSPOSE && slot_exchange_cfg<G, MR, CPL>() && G == 4 && CE == 4 && (CE == CPL || SQFA_SLOT_TRANSPOSE >= 2);
+  return SQFA_SLOT_TRANSPOSE && slot_exchange_cfg<G, MR, CPL>() && CE == 4 &&
+         ((G == 4 && (CE == CPL || SQFA_SLOT_TRANSPOSE >= 2)) || (G == 8 && SQFA_SLOT_TRANSPOSE_G8));
 }
+// development switch: transpose back at the end of every sweep (same pair order in every sweep, twice the LDS passes)
+#ifndef SQFA_SLOT_TRANSPOSE_TWICE
+#define SQFA_SLOT_TRANSPOSE_TWICE 0
+#endif
 constexpr int kTransposePitch = 72;
 constexpr int kTransposeElems = 3 * kTransposePitch + 64;  // elements of wave-private LDS `buf` must provide
 template <typename T, int MR, int CPL>
@@ -906,6 +919,11 @@ __device__ __forceinline__ void exchange_sweep(T (&x)[CPL][MR], T (&nrm)[CPL], T
     transpose_slots<T, MR, CPL>(x, nrm, D, buf);
 #endif
     slot_rounds<T, MR, CPL, CE, 1, RS>(x, nrm, D, tol2, big);
+    if constexpr (G == 8) {  // lanes that differ in bit 2: every slot pair, two owners
+      if constexpr (paired_steps<T, G, MR>()) cross_round_paired<T, MR, CPL, 4, SWZ, LONE_LAST, 0, RS>(x, nrm, D, 4, tol2, big);
+      else cross_round<T, MR, CPL, 4, SWZ, LONE_LAST, RS>(x, nrm, D, 4, tol2, big);
+    }
+    if constexpr (SQFA_SLOT_TRANSPOSE_TWICE != 0) transpose_slots<T, MR, CPL>(x, nrm, D, buf);
   } else {
     same_slot_rounds<T, MR, G, CPL, SWZ, LONE_LAST, RS>(x, nrm, D, tol2, big);
   }
@@ -1303,7 +1321,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
 #endif
     }
     if constexpr (slot_transpose_cfg<G, MR, CPL>()) {
-      if (sweeps & 1) transpose_slots<T, MR, CPL>(x, nrm, D, li);  // back to the dealt positions (wave-uniform branch)
+      if (!SQFA_SLOT_TRANSPOSE_TWICE && (sweeps & 1)) transpose_slots<T, MR, CPL>(x, nrm, D, li);  // back to the dealt positions (wave-uniform branch)
     }
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
