@@ -335,13 +335,15 @@ __device__ __forceinline__ void rot_scaled(T no, T nr, T gh, T Dx, T Dy, T tol2,
 // The same rotation for two columns of ONE lane (local_step2), written in d = nr - no and g4 = 4 g2 = (2 gh)^2 Dx Dy so that
 // no halving is left in the chain:  h4 = sqrt(d^2 + g4) = 2 h,  w = 1 + |d| / h4 = 2 u,  k/2 = 1 / (h4 w).  Returns u,
 // kgh = k gh (the caller's a1 = -kgh Dy, a2 = kgh Dx) and kg4 = (k/2) g4 = 2 k g2 (norm updates -+ kg4 / 2, folded into an
-// fma).  One owner: no tie to break (d = +0 for equal norms: the sign bit a lone owner would pick anyway), and the
-// "rotate at all" test is an absolute floor on g4 -- it only has to keep 0/0 out (zero and identity-padded columns have
-// g4 = 0 exactly); rotations below the rounding noise are harmless and cost the same as a skipped one.  24 instructions
-// instead of the 30 of rot_scaled + its caller; at 4 x 4 slots every rotation of a sweep is of this kind.
+// fma).  One owner: no tie to break (d = +0 for equal norms: the sign bit a lone owner would pick anyway).  There is no
+// "rotate at all?" select either: |d| enters as |d| + RotFloor (1e-18 of a norm: invisible), which turns the one case the select
+// guarded -- d = 0 and gh = 0 exactly: zero columns, identity-padded columns, two copies of one class -- into |d| / h4 = 1, i.e.
+// u = 1 with kgh = kg4 = (large but finite) x 0 = 0: the identity.  Rotations below the rounding noise are harmless and cost what
+// a skipped one costs.  24 instructions instead of the 30 of rot_scaled + its caller; at 4 x 4 slots every rotation of a sweep
+// is of this kind.
 template <typename T> struct RotFloor;
-template <> struct RotFloor<float> { static constexpr float v = 1.0e-32f; };
-template <> struct RotFloor<double> { static constexpr double v = 1.0e-290; };
+template <> struct RotFloor<float> { static constexpr float v = 1.0e-18f; };     // squared: 1e-36, a normal float
+template <> struct RotFloor<double> { static constexpr double v = 1.0e-150; };
 template <typename T, int MR>
 __device__ __forceinline__ void rot_local(T no, T nr, T gh, T Dx, T Dy, T& u, T& kgh, T& kg4, bool& big) {
   using R = Real<T>;
@@ -350,14 +352,13 @@ __device__ __forceinline__ void rot_local(T no, T nr, T gh, T Dx, T Dy, T& u, T&
 #endif
   const T e = gh + gh;
   const T g4 = e * e * (Dx * Dy);
-  const bool rot = g4 > RotFloor<T>::v;
   big = big || (g4 > (T(4) * R::template early2<MR>()) * (no * nr));
   const T d = nr - no;
-  const T rh4 = R::rsq(R::fma_(d, d, g4));
-  const T w = R::fma_(R::abs_(d), rh4, T(1));
-  const T kp = R::copysign_(rh4 * R::rcp(w), d);
-  const T k = rot ? kp : T(0);
-  u = rot ? T(0.5) * w : T(1);
+  const T ad = R::abs_(d) + RotFloor<T>::v;
+  const T rh4 = R::rsq(R::fma_(ad, ad, g4));
+  const T w = R::fma_(ad, rh4, T(1));
+  const T k = R::copysign_(rh4 * R::rcp(w), d);
+  u = T(0.5) * w;
   kgh = k * e;
   kg4 = k * g4;
 }
