@@ -43,7 +43,7 @@ def main(write_csv, fetch_csv, out):
     pr["algorithmic_bytes_per_launch"] = 4 * (2 * C * K * K + 1)
     pr["note"] = (
         "traffic = the slab of the deterministic two-pass reduction (4032 tiles x 24 lower triangles x 136 x 4 B "
-        "= 52.6 MB written here, read back by finalize_kernel) + the L/Linv factors + 1 VGPR spilled once per workgroup"
+        "= 52.6 MB written here, read back by finalize_kernel) + the L/Linv factors + the register spills of the backward phase (10 VGPRs per wave round at m=16, written back: ~48 MB)"
     )
     doc = {
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace) on "
