@@ -777,6 +777,29 @@ template <int G, int CE> constexpr bool slot_exchange_ok() {  // CE: the slots t
 template <int G, int MR, int CPL> constexpr bool slot_exchange_cfg() {
   return slot_exchange_ok<G, (z_visits_cfg<G, MR, CPL>() ? CPL - 1 : CPL)>();
 }
+// Compile-time proof of the schedule for one group shape: walking the G phases, every pair of columns from DIFFERENT slots
+// shares a lane in exactly one phase, columns of the same slot never do, and the last exchange brings every column home.
+template <int G, int CE> constexpr bool slot_exchange_schedule_ok() {
+  constexpr int g = ilog2(G);
+  int lane_of[G * CE] = {};  // current lane of the column dealt to (l, s): index l * CE + s
+  for (int l = 0; l < G; ++l)
+    for (int s = 0; s < CE; ++s) lane_of[l * CE + s] = l;
+  int met[G * CE][G * CE] = {};
+  for (int ph = 1; ph <= G; ++ph) {
+    const int delta = ph == G ? G / 2 : (ph & -ph);
+    for (int l = 0; l < G; ++l)
+      for (int s = 1; s < CE; ++s) lane_of[l * CE + s] ^= gf2_mul(s, delta, g);
+    for (int a = 0; a < G * CE; ++a)
+      for (int b = a + 1; b < G * CE; ++b)
+        if (lane_of[a] == lane_of[b]) ++met[a][b];
+  }
+  for (int a = 0; a < G * CE; ++a) {
+    if (lane_of[a] != a / CE) return false;  // not home again
+    for (int b = a + 1; b < G * CE; ++b)
+      if (met[a][b] != ((a % CE) != (b % CE) ? 1 : 0)) return false;
+  }
+  return true;
+}
 // exchange slots S_..CE-1 for the phase step DELTA
 template <typename T, int MR, int G, int CPL, int CE, int SWZ, int DELTA, int S_ = 1>
 __device__ __forceinline__ void exchange_slots(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL]) {
@@ -914,6 +937,7 @@ template <typename T, int MR, int G, int CPL, bool LONE_LAST, bool TRANSPOSE = f
 __device__ __forceinline__ void exchange_sweep(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], T tol2, bool& big, T* buf = nullptr) {
   constexpr int CE = tournament_slots<CPL, LONE_LAST>();
   constexpr int SWZ = swizzled_rows_of_8<T, G, MR, true>();
+  static_assert(slot_exchange_schedule_ok<G, CE>(), "slot-exchange schedule does not cover every pair exactly once");
   exchange_phases<T, MR, G, CPL, CE, SWZ, RS>(x, nrm, D, tol2, big);
   if constexpr (TRANSPOSE) {
 #ifndef SQFA_ABL_NO_EXCHANGE
