@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 4 A/B: slot-exchange ordering of the sweeps (pair_kernel.hpp, exchange_slots) against the two-owner tournament.
-# variants/build/r4_base.so = the library before the change; "-" = the installed library.
+# variants/build/r4_base.so = the library before the change (git worktree add /tmp/base 84e2754 && make -C /tmp/base/sqfa_amd/csrc &&
+# cp /tmp/base/sqfa_amd/lib/libsqfa_hip.so variants/build/r4_base.so; variants/ is git-ignored); "-" = the installed library.
 set -e
 V=variants/build
 O=gpurun_out/r4/exchange.txt
