@@ -6,14 +6,20 @@
 // wave-round in LDS and read as broadcasts), with TI = 64/G different A classes i.
 //
 // Per pair (A = S_i, B = S_j = L_j L_j^T):
-//   1. X = L_j^-1 L_i                  (lower triangular; M = X X^T = L_j^-1 A L_j^-T)
+//   1. X = L_j^-1 F_i                  (F_i = L_i, or L_i V_i with orthogonal columns after the class factor
+//                                        pass; M = X X^T = L_j^-1 A L_j^-T either way)
 //   2. one-sided (Hestenes) Jacobi on the COLUMNS of X, held in registers: each lane owns
-//      CPL column slots of all MR rows; rotations between columns of one lane are local,
-//      rotations between lanes follow an XOR tournament (lane^s, slot^t); partner columns
-//      travel through DPP (2 VALU issue slots per move on gfx950) or ds_swizzle (the
-//      otherwise idle LDS crossbar), in a ratio tuned per group size.  Columns carry a
-//      squared scale (x = sqrt(D) x^), so a rotation costs one fma per element and its
-//      parameters one v_rsq + one v_rcp (see rot_scaled).
+//      CPL column slots of all MR rows; rotations between columns of one lane are local.
+//      Since round 4 the columns TRAVEL between the lanes of a group (exchange_slots: slot s is
+//      exchanged with the same slot of lane ^ mask, masks from GF(2^g) arithmetic) so that every pair
+//      of columns from different slots is local once per sweep; same-slot pairs become local through
+//      an LDS transposition of the (lane, slot) blocks (transpose_slots: 4 x 4 groups) or keep the
+//      two-owner steps of the original XOR tournament (lane^s, slot^t: cross_step2; also the whole
+//      sweep of the few geometries the exchange scheme does not cover).  Cross-lane moves go
+//      through DPP (1.63 VALU issue slots per move on gfx950) or ds_swizzle (the LDS crossbar, off
+//      the VALU), in a ratio tuned per group size.  Columns carry a squared scale (x = sqrt(D) x^),
+//      so a rotation costs one fma per element and its parameters one v_rsq + one v_rcp
+//      (rot_local for one-owner rotations, rot_scaled for two owners).
 //      On exit X J = Y with orthogonal columns y_k = sigma_k v_k: lambda_k = |y_k|^2 are
 //      the generalized eigenvalues of (A,B), v_k the eigenvectors of M.
 //   3. d2 = scale * sum log(lambda)^2, D = sqrt(d2+eps) | d2
@@ -26,9 +32,9 @@
 //      flush the A side to the slab; finalize_kernel reduces slabs per class in a fixed order.
 //
 // Cost model behind the choices (tools/ubench/*.hip, MI355X): plain VALU op = 1 issue slot
-// (~2.5 cycles/wave-instr at >= 2 waves/SIMD, 5.4 for a lone wave), DPP op = 2 slots,
-// v_rsq/v_rcp/v_sqrt = 4 slots, v_pk_fma_f32 = 2 slots for 2 flops, ds_swizzle ~2.3 cycles
-// per CU (LDS pipe, off the VALU), ds_bpermute ~6.
+// (~2.5 cycles/wave-instr at >= 2 waves/SIMD, 5.4 for a lone wave), DPP op = 1.63 slots,
+// v_rsq/v_rcp/v_sqrt = 3.2 slots, v_pk_fma_f32 = 1.7 slots for 2 flops, v_permlane16/32_swap 3.2,
+// ds_swizzle ~2.3 cycles per CU (LDS pipe, off the VALU), ds_bpermute ~6; LDS float atomics: unusable.
 //
 // Replaces: src/sqfa/linalg.py:19-70,144-162, src/sqfa/distances.py:46-89,177-237,
 // src/sqfa/_optim.py:16-30,88-96 of the reference and the autograd backward of that chain.
