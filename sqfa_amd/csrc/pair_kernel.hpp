@@ -1006,6 +1006,9 @@ struct OuterProduct {
   }
 };
 
+#ifndef SQFA_BACK_SCHED_BARRIER
+#define SQFA_BACK_SCHED_BARRIER -1  // -1: by size, 0: never, 1: always
+#endif
 #ifndef SQFA_SWAP_MIN
 #define SQFA_SWAP_MIN 16
 #endif
@@ -1463,6 +1466,10 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
         }
 #pragma unroll
         for (int c = 0; c < CPL; ++c) x[c][r] = acc[c];
+        // One scheduling barrier per row where it was measured to pay: left alone, the scheduler hoists the strided LDS reads
+        // of many rows and the backward phase spills (m=32: 43 VGPRs -> 0 and 6.38 -> 6.29 ms; m=16: 10 -> 0 but 0.686 -> 0.692 ms,
+        // m=17 / 24 / 33 / float64 within +-0.3 %: off there -- profiles/r4_pairs_slot_exchange.txt)
+        if constexpr (SQFA_BACK_SCHED_BARRIER > 0 || (SQFA_BACK_SCHED_BARRIER < 0 && sizeof(T) == 4 && MR == 32)) __builtin_amdgcn_sched_barrier(0);
       }
       // rank-one sums (lower triangles) with transposing tree reductions:
       //   A side: over the G lanes of the pair; lane g finishes entries idx = G*i + g and adds
