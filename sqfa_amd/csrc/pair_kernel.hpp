@@ -1467,9 +1467,10 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
 #pragma unroll
         for (int c = 0; c < CPL; ++c) x[c][r] = acc[c];
         // One scheduling barrier per row where it was measured to pay: left alone, the scheduler hoists the strided LDS reads
-        // of many rows and the backward phase spills (m=32: 43 VGPRs -> 0 and 6.38 -> 6.29 ms; m=16: 10 -> 0 but 0.686 -> 0.692 ms,
-        // m=17 / 24 / 33 / float64 within +-0.3 %: off there -- profiles/r4_pairs_slot_exchange.txt)
-        if constexpr (SQFA_BACK_SCHED_BARRIER > 0 || (SQFA_BACK_SCHED_BARRIER < 0 && sizeof(T) == 4 && MR == 32)) __builtin_amdgcn_sched_barrier(0);
+        // of many rows and the backward phase spills (m=32: 43 VGPRs -> 0 and 6.38 -> 6.29 ms, m=48 154 -> 0 and -1.5 %, m=64
+        // 260 -> 19 and -1.3 %, m=33 18 -> 10 and +0.3 %; m=16: 10 -> 0 but 0.686 -> 0.692 ms, m=17 / 24 / float64 within
+        // +-0.3 %: float32 from 32 rows on -- profiles/r4_pairs_slot_exchange.txt)
+        if constexpr (SQFA_BACK_SCHED_BARRIER > 0 || (SQFA_BACK_SCHED_BARRIER < 0 && sizeof(T) == 4 && MR >= 32)) __builtin_amdgcn_sched_barrier(0);
       }
       // rank-one sums (lower triangles) with transposing tree reductions:
       //   A side: over the G lanes of the pair; lane g finishes entries idx = G*i + g and adds
