@@ -416,6 +416,9 @@ template <int RS, typename T> __device__ __forceinline__ T row_total(T v) {
 #ifndef SQFA_Z_VISITS
 #define SQFA_Z_VISITS 1
 #endif
+#ifndef SQFA_Z_PRIO
+#define SQFA_Z_PRIO -1  // wave priority while the lone column moves; -1: 3 for float32 (m=33 8.91 -> 8.75 ms, m=17 1.094 -> 1.090), 0 for float64 (2.958 -> 2.973 with 3)
+#endif
 template <int G, int MR, int CPL> constexpr bool z_visits_cfg() {
   return SQFA_Z_VISITS && G > 1 && MR == G * (CPL - 1) + 1;
 }
@@ -736,10 +739,13 @@ __device__ __forceinline__ void z_visits(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[
     z_visit_steps<T, MR, CPL, 0, RS>(x, nrm, D, tol2, big);
     constexpr int NXT = V + 1;
     constexpr int BIT = (NXT == G) ? G / 2 : (NXT & -NXT);
+    constexpr int ZP = SQFA_Z_PRIO >= 0 ? SQFA_Z_PRIO : (sizeof(T) == 4 ? 3 : 0);
+    if (ZP) __builtin_amdgcn_s_setprio(ZP);
 #pragma unroll
     for (int r = 0; r < MR; ++r) x[Z][r] = lane_xor_row<BIT, SWZ>(x[Z][r], BIT, r);
     nrm[Z] = lane_xor<BIT>(nrm[Z], BIT);
     D[Z] = lane_xor<BIT>(D[Z], BIT);
+    if (ZP) __builtin_amdgcn_s_setprio(0);
     z_visits<T, MR, G, CPL, SWZ, V + 1, RS>(x, nrm, D, tol2, big);
   }
 }
@@ -764,6 +770,17 @@ __device__ __forceinline__ void z_visits(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[
 // same 96 MR fmas; at 8 x 4: 52 MR instead of 112 MR.  Needs 2 <= CE <= G slots (CE: the slots of the tournament).
 #ifndef SQFA_SLOT_EXCHANGE
 #define SQFA_SLOT_EXCHANGE 1
+#endif
+// The bursts of cross-lane moves (slot exchanges, the transposition's LDS passes) are issued at raised wave priority, like the
+// fetch bursts of the two-owner steps: the sooner a wave's moves are in flight, the more of their latency its SIMD neighbours'
+// arithmetic covers.  C=1000, pair kernel ms without -> with priority 3: m=16 0.708 -> 0.704, m=17 1.101 -> 1.081, m=24 2.528 ->
+// 2.375, m=32 6.26 -> 6.03, m=33 9.16 -> 8.88, m=48 (C=300) 3.135 -> 2.855; m=12 and float64 unchanged (priority 1: the same).
+#ifndef SQFA_EXCH_PRIO
+#define SQFA_EXCH_PRIO 3
+#endif
+
+#ifndef SQFA_PHASE_BARRIER
+#define SQFA_PHASE_BARRIER 0
 #endif
 #ifndef SQFA_SLOT_EXCHANGE_MAX_G
 #define SQFA_SLOT_EXCHANGE_MAX_G 16
@@ -846,7 +863,16 @@ __device__ __forceinline__ void exchange_phases(T (&x)[CPL][MR], T (&nrm)[CPL], 
   if constexpr (PH <= G) {
     constexpr int DELTA = PH == G ? G / 2 : (PH & -PH);
 #ifndef SQFA_ABL_NO_EXCHANGE
+#if SQFA_EXCH_PRIO
+    __builtin_amdgcn_s_setprio(SQFA_EXCH_PRIO);
+#endif
     exchange_slots<T, MR, G, CPL, CE, SWZ, DELTA>(x, nrm, D);
+#if SQFA_EXCH_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#endif
+#if SQFA_PHASE_BARRIER
+    __builtin_amdgcn_sched_barrier(0);
 #endif
     slot_rounds<T, MR, CPL, CE, 1, RS>(x, nrm, D, tol2, big);
     exchange_phases<T, MR, G, CPL, CE, SWZ, RS, PH + 1>(x, nrm, D, tol2, big);
@@ -947,7 +973,16 @@ __device__ __forceinline__ void exchange_sweep(T (&x)[CPL][MR], T (&nrm)[CPL], T
   exchange_phases<T, MR, G, CPL, CE, SWZ, RS>(x, nrm, D, tol2, big);
   if constexpr (TRANSPOSE) {
 #ifndef SQFA_ABL_NO_EXCHANGE
+#if SQFA_EXCH_PRIO
+    __builtin_amdgcn_s_setprio(SQFA_EXCH_PRIO);
+#endif
     transpose_slots<T, MR, CPL>(x, nrm, D, buf);
+#if SQFA_EXCH_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#endif
+#if SQFA_PHASE_BARRIER
+    __builtin_amdgcn_sched_barrier(0);
 #endif
     slot_rounds<T, MR, CPL, CE, 1, RS>(x, nrm, D, tol2, big);
     if constexpr (G == 8) {  // lanes that differ in bit 2: every slot pair, two owners
