@@ -645,6 +645,9 @@ __device__ __forceinline__ void cross_rounds_static(T (&x)[CPL][MR], T (&nrm)[CP
 // the (up to two) pairs of a round that are handled together touch disjoint slots, so their inner
 // products and parameter chains are independent instruction streams (the plain c1 < c2 double loop
 // is one long dependency chain through slot 0: fine with four waves per SIMD, exposed with two).
+#ifndef SQFA_LOCAL_PARAM_PRIO
+#define SQFA_LOCAL_PARAM_PRIO -1  // -1: by element type
+#endif
 #ifndef SQFA_LOCAL_TOURNAMENT
 #define SQFA_LOCAL_TOURNAMENT 1
 #endif
@@ -674,6 +677,11 @@ __device__ __forceinline__ void local_step2(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
     for (int q = 0; q < NS; ++q) gh[q] = row_total<RS>(gh[q]);
   }
   T a1[2], a2[2];
+  // the parameter chains (serial, two transcendentals each) run at raised wave priority: float32 m=16 0.706 -> 0.682 ms, m=17
+  // 1.070 -> 1.024, m=32 6.14 -> 5.98; float64 m=16 1.584 -> 1.594: off there.  (Priority 3: the same; inner products included:
+  // slightly worse.)
+  constexpr int LP = SQFA_LOCAL_PARAM_PRIO >= 0 ? SQFA_LOCAL_PARAM_PRIO : (sizeof(T) == 4 ? 1 : 0);
+  if (LP) __builtin_amdgcn_s_setprio(LP);
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
     T u, kgh, kg4;
@@ -685,6 +693,7 @@ __device__ __forceinline__ void local_step2(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
     nrm[ca[q]] = R::fma_(T(-0.5), kg4, nrm[ca[q]]);
     nrm[cb[q]] = R::fma_(T(0.5), kg4, nrm[cb[q]]);
   }
+  if (LP) __builtin_amdgcn_s_setprio(0);
 #ifdef SQFA_ABL_NO_UPDATE  // development: timing ablation, wrong results (two rows keep the parameters alive)
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
