@@ -499,6 +499,14 @@ __device__ __forceinline__ void cross_round(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
 #ifndef SQFA_PARAM_PRIO
 #define SQFA_PARAM_PRIO 1
 #endif
+#ifndef SQFA_PARAM_PRIO_ALL
+#define SQFA_PARAM_PRIO_ALL -1  // -1: by size
+#endif
+// wave priority 1 in the phases around the sweeps -- bit 0: X formation, bit 1: back-transform, bit 2: rank-one sums; -1: float32
+// rank-one sums (m=16 0.688 -> 0.677 ms, m=17 -0.6 %, m=24 -0.3 %), all three from 32 rows on (m=32 5.96 -> 5.87; bit 2 alone -0.2 %)
+#ifndef SQFA_BWD_PRIO
+#define SQFA_BWD_PRIO -1
+#endif
 template <typename T, int MR, int CPL, int S, int SWZ, bool LONE_LAST, int C0, int C1, int T_, int RS = 0>
 __device__ __forceinline__ void cross_step2(T (&x)[CPL][MR], T (&nrm)[CPL], T (&D)[CPL], int s, T tol2, T tie, bool& big) {
   using R = Real<T>;
@@ -529,7 +537,8 @@ __device__ __forceinline__ void cross_step2(T (&x)[CPL][MR], T (&nrm)[CPL], T (&
     const int c = cs[q];
     // m=16 (four waves per SIMD): the inner product + parameter chain, the latency-critical part of a
     // step, also runs at raised priority (-1.4 %; +1 % at m=17, no change at m=32: off there)
-    constexpr bool PARAM_PRIO = SQFA_PARAM_PRIO != 0 && MR == 16 && CPL == 4 && sizeof(T) == 4;
+    // (round 4, slot-exchange sweeps: every float32 row below 32 rows -- m=17 -0.7 %, m=24 -0.8 %; m=32 +0.4 %)
+    constexpr bool PARAM_PRIO = SQFA_PARAM_PRIO != 0 && sizeof(T) == 4 && (SQFA_PARAM_PRIO_ALL > 0 || (SQFA_PARAM_PRIO_ALL < 0 && MR < 32) || (MR == 16 && CPL == 4));
     if (PARAM_PRIO) __builtin_amdgcn_s_setprio(SQFA_PARAM_PRIO);
     const T gh = row_total<RS>(dot_cols<T, MR>(x[c], rv[q]));
     T u1, k1, g21;
@@ -1247,6 +1256,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
 
   const T tol2 = R::kEps * R::kEps * T(MR);
   const T scale = param_scale<T>(p), eps = param_eps<T>(p);
+  constexpr int BWD_PRIO = SQFA_BWD_PRIO >= 0 ? SQFA_BWD_PRIO : (sizeof(T) == 4 ? (MR >= 32 ? 7 : 4) : 0);
 
   // per-wave partial results, wave-uniform so that they live in SGPRs across the sweep loop
   T loss_acc = T(0);
@@ -1296,6 +1306,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
 #pragma unroll
       for (int k = 0; k < MR; ++k) x[c][k] = real_col ? src[k] : T(0);
     }
+    if (BWD_PRIO & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int r = MR - 1; r >= 0; --r) {
       T acc[CPL];
@@ -1318,6 +1329,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
       for (int c = 0; c < CPL; ++c) x[c][r] = acc[c];
     }
 
+    if (BWD_PRIO & 1) __builtin_amdgcn_s_setprio(0);
     // ---- 2. one-sided Jacobi ---------------------------------------------------------
     T nrm[CPL], D[CPL];  // true squared norms; squared column scales, x_true = sqrt(D) x (see rot_scaled)
 #pragma unroll
@@ -1497,6 +1509,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
         }
       }
       // u~ = L_j^-T y in place: u~[r] = sum_{q>=r} Linv[q][r] y[q], rows in ascending order
+      if (BWD_PRIO & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int r = 0; r < MR; ++r) {
         T acc[CPL];
@@ -1516,6 +1529,8 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
         // +-0.3 %: float32 from 32 rows on -- profiles/r4_pairs_slot_exchange.txt)
         if constexpr (SQFA_BACK_SCHED_BARRIER > 0 || (SQFA_BACK_SCHED_BARRIER < 0 && sizeof(T) == 4 && MR >= 32)) __builtin_amdgcn_sched_barrier(0);
       }
+      if (BWD_PRIO & 2) __builtin_amdgcn_s_setprio(0);
+      if (BWD_PRIO & 4) __builtin_amdgcn_s_setprio(1);
       // rank-one sums (lower triangles) with transposing tree reductions:
       //   A side: over the G lanes of the pair; lane g finishes entries idx = G*i + g and adds
       //           them to this wave's private LDS accumulator of class i
@@ -1544,6 +1559,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
         if (lane < TRI) gb[lane] = acc;
       }
 #endif
+      if (BWD_PRIO & 4) __builtin_amdgcn_s_setprio(0);
     }
   }
 
