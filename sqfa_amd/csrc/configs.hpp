@@ -29,13 +29,14 @@
 #define SQFA_ROW_F32_24(X) X(float, 24, 8, 3, 8, 4)
 #endif
 #ifndef SQFA_ROW_F32_32
-#define SQFA_ROW_F32_32(X) X(float, 32, 8, 4, 4, 1)
+// round 4: two waves per workgroup (with the slot-exchange sweeps: 5.70 -> 5.51 ms at C=1000; four: 5.67, 8-wide tiles: 5.67-5.83)
+#define SQFA_ROW_F32_32(X) X(float, 32, 8, 4, 4, 2)
 #endif
 #ifndef SQFA_ROW_F32_33
-#define SQFA_ROW_F32_33(X) X(float, 33, 8, 5, 4, 1)
+#define SQFA_ROW_F32_33(X) X(float, 33, 8, 5, 4, 2)  // two waves: 8.29 -> 8.21 ms (four: 8.67)
 #endif
 #ifndef SQFA_ROW_F32_48
-#define SQFA_ROW_F32_48(X) X(float, 48, 16, 3, 4, 1)
+#define SQFA_ROW_F32_48(X) X(float, 48, 16, 3, 4, 2)  // round 4: two waves per workgroup, 2.615 -> 2.545 ms at C=300
 #endif
 #ifndef SQFA_ROW_F32_64
 #define SQFA_ROW_F32_64(X) X(float, 64, 32, 2, 4, 2)
