@@ -1256,7 +1256,8 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void pair_tile_kernel
 
   const T tol2 = R::kEps * R::kEps * T(MR);
   const T scale = param_scale<T>(p), eps = param_eps<T>(p);
-  constexpr int BWD_PRIO = SQFA_BWD_PRIO >= 0 ? SQFA_BWD_PRIO : (sizeof(T) == 4 ? (MR >= 32 ? 7 : 4) : 0);
+  // (float64: all three at m=16 only -- 1.572 -> 1.544 ms; m=17 +0.5 %, m=12 unchanged: off there)
+  constexpr int BWD_PRIO = SQFA_BWD_PRIO >= 0 ? SQFA_BWD_PRIO : (sizeof(T) == 4 ? (MR >= 32 ? 7 : 4) : (MR == 16 ? 7 : 0));
 
   // per-wave partial results, wave-uniform so that they live in SGPRs across the sweep loop
   T loss_acc = T(0);
